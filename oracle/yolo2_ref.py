@@ -1,0 +1,679 @@
+"""CPU ORACLE -- test infrastructure only, never shipped, never the thing measured.
+
+NumPy restatement of the YOLOv2 train+detect hot path of ruiminshen/yolo-tf.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; the product package ``yolo_tf_amd`` never does.
+
+Pinning status (see DESIGN.md section "Oracle"):
+  * PINNED against the reference itself (functions importable here without TensorFlow, golden
+    vectors in tests/golden/ produced by tests/golden/make_golden.py from /root/reference):
+    ``iou``, ``non_max_suppress``, ``transform_labels``, ``calc_cell_xy``,
+    ``per_image_standardization``, ``reorg`` (the reference's own 4x4 known-answer test,
+    model/yolo2/function.py:32-47).
+  * PARITY UNPINNED by the reference (the arithmetic lives in TensorFlow 1.0 / tf.contrib.slim,
+    unpinned version, not vendored under /root/reference, cannot run here): conv2d, batch_norm,
+    max_pool2d, Model decode, Objectives, backward, optimizers.  These follow the published
+    TF-1.0 semantics ([TF-sem] notes) and are cross-checked in tests against torch-CPU fp64
+    autograd and analytic known answers, not against TensorFlow.
+
+All tensors are NHWC; conv weights are HWIO ``[kh, kw, Cin, Cout]`` (parse_darknet_yolo2.py:95-97).
+Every function works in the dtype of its inputs (float32 for parity runs, float64 for
+gradient cross-checks).
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# elementwise / layout ops
+# --------------------------------------------------------------------------------------
+
+def leaky_relu(x, alpha=.1):
+    """model/yolo/function.py:21-24 -- max(x, alpha*x)."""
+    return np.maximum(x, x.dtype.type(alpha) * x)
+
+
+def leaky_relu_grad(x, dy, alpha=.1):
+    """[TF-sem] tf.maximum(x, a*x) gradient: MaximumGrad routes to the first argument where
+    x >= a*x, i.e. x >= 0 (ties at 0 take slope 1), else slope alpha."""
+    return np.where(x >= 0, dy, x.dtype.type(alpha) * dy)
+
+
+def reorg(x, stride=2):
+    """model/yolo2/function.py:22-29 -- reshape/transpose/reshape; closed form
+    out[b,y,x,(sy*2+sx)*C+c] = in[b,2y+sy,2x+sx,c]."""
+    b, h, w, c = x.shape
+    _h, _w = h // stride, w // stride
+    t = x.reshape(b, _h, stride, _w, stride, c)
+    t = t.transpose(0, 1, 3, 2, 4, 5)
+    return t.reshape(b, _h, _w, stride * stride * c)
+
+
+def reorg_grad(dy, stride=2):
+    """Inverse permutation of :func:`reorg` (it is a pure move)."""
+    b, _h, _w, cc = dy.shape
+    c = cc // (stride * stride)
+    t = dy.reshape(b, _h, _w, stride, stride, c)
+    t = t.transpose(0, 1, 3, 2, 4, 5)
+    return t.reshape(b, _h * stride, _w * stride, c)
+
+
+# --------------------------------------------------------------------------------------
+# convolution (slim.layers.conv2d call sites model/yolo2/inference.py:37-48,73-118)
+# [TF-sem] stride 1, padding SAME, no dilation, cross-correlation (no kernel flip).
+# --------------------------------------------------------------------------------------
+
+def _shifted(x, dh, dw):
+    """x shifted so that out[b,h,w] = x[b,h+dh,w+dw] with zero fill (SAME padding)."""
+    b, h, w, c = x.shape
+    out = np.zeros_like(x)
+    hs, he = max(0, -dh), min(h, h - dh)
+    ws, we = max(0, -dw), min(w, w - dw)
+    if hs < he and ws < we:
+        out[:, hs:he, ws:we, :] = x[:, hs + dh:he + dh, ws + dw:we + dw, :]
+    return out
+
+
+def conv2d(x, w):
+    """y[b,h,w,k] = sum_{r,s,c} x[b,h+r-ph,w+s-pw,c] * W[r,s,c,k]; odd kernels, zero pad."""
+    kh, kw, cin, cout = w.shape
+    b, h, wd, _ = x.shape
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    y = np.zeros((b, h, wd, cout), dtype=x.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            xs = _shifted(x, r - ph, s - pw).reshape(-1, cin)
+            y += (xs @ w[r, s]).reshape(b, h, wd, cout)
+    return y
+
+
+def conv2d_dgrad(dy, w):
+    """dx[b,h,w,c] = sum_{r,s,k} dy[b,h-(r-ph),w-(s-pw),k] * W[r,s,c,k]."""
+    kh, kw, cin, cout = w.shape
+    b, h, wd, _ = dy.shape
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    dx = np.zeros((b, h, wd, cin), dtype=dy.dtype)
+    for r in range(kh):
+        for s in range(kw):
+            ds = _shifted(dy, -(r - ph), -(s - pw)).reshape(-1, cout)
+            dx += (ds @ w[r, s].T).reshape(b, h, wd, cin)
+    return dx
+
+
+def conv2d_wgrad(x, dy, kh, kw):
+    """dW[r,s,c,k] = sum_{b,h,w} x[b,h+r-ph,w+s-pw,c] * dy[b,h,w,k]."""
+    cin, cout = x.shape[-1], dy.shape[-1]
+    ph, pw = (kh - 1) // 2, (kw - 1) // 2
+    dw = np.zeros((kh, kw, cin, cout), dtype=x.dtype)
+    d2 = dy.reshape(-1, cout)
+    for r in range(kh):
+        for s in range(kw):
+            xs = _shifted(x, r - ph, s - pw).reshape(-1, cin)
+            dw[r, s] = xs.T @ d2
+    return dw
+
+
+# --------------------------------------------------------------------------------------
+# batch norm (closure model/yolo2/inference.py:62-66 -> slim.batch_norm(center, scale=True,
+# epsilon=1e-5, is_training)).  [TF-sem] decay 0.999, tf.nn.moments (biased variance),
+# y = gamma*(x-mean)/sqrt(var+eps)+beta, EMA with the biased batch variance.
+# --------------------------------------------------------------------------------------
+BN_EPS = 1e-5
+BN_DECAY = 0.999
+
+
+def bn_moments(x):
+    n = x.shape[0] * x.shape[1] * x.shape[2]
+    x2 = x.reshape(n, -1)
+    acc = x2.astype(np.float64)
+    mean = acc.mean(0)
+    var = ((acc - mean) ** 2).mean(0)
+    return mean.astype(x.dtype), var.astype(x.dtype)
+
+
+def bn_apply(x, mean, var, gamma, beta, eps=BN_EPS):
+    t = x.dtype.type
+    inv = t(1) / np.sqrt(var + t(eps))
+    return (x - mean) * (inv * gamma) + beta
+
+
+def bn_ema(moving, batch, decay=BN_DECAY):
+    """[TF-sem] assign_moving_average: moving -= (1-decay)*(moving-batch)."""
+    t = moving.dtype.type
+    return moving - (moving - batch) * t(1 - decay)
+
+
+def bn_train_bwd(x, mean, var, gamma, dz, eps=BN_EPS):
+    """Backward of y = gamma*xhat+beta with batch statistics; returns dx, dgamma, dbeta."""
+    t = x.dtype.type
+    n = x.shape[0] * x.shape[1] * x.shape[2]
+    inv = t(1) / np.sqrt(var + t(eps))
+    xhat = (x - mean) * inv
+    dz64 = dz.reshape(n, -1).astype(np.float64)
+    dbeta = dz64.sum(0).astype(x.dtype)
+    dgamma = (dz64 * xhat.reshape(n, -1)).sum(0).astype(x.dtype)
+    dx = (gamma * inv) * (dz - dbeta / t(n) - xhat * (dgamma / t(n)))
+    return dx, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------------------
+# max pool 2x2 (slim.layers.max_pool2d model/yolo2/inference.py:38,42,74,83,96; arg_scope
+# padding='SAME').  [TF-sem] stride 2 on even extents needs no padding; the tiny model's
+# stride-1 pool pads 0 before / 1 after and the pad never wins the max.  Backward routes the
+# gradient to the first maximum in window scan order (row-major).
+# --------------------------------------------------------------------------------------
+
+def _pool_windows(x, stride):
+    b, h, w, c = x.shape
+    if stride == 2:
+        assert h % 2 == 0 and w % 2 == 0
+        xp = x
+        oh, ow = h // 2, w // 2
+    else:
+        xp = np.full((b, h + 1, w + 1, c), -np.inf, dtype=x.dtype)
+        xp[:, :h, :w, :] = x
+        oh, ow = h, w
+    win = np.stack([xp[:, dy:dy + oh * stride:stride, dx:dx + ow * stride:stride, :]
+                    for dy in range(2) for dx in range(2)], axis=0)  # [4, b, oh, ow, c]
+    return win, oh, ow
+
+
+def max_pool(x, stride=2):
+    win, _, _ = _pool_windows(x, stride)
+    return win.max(0)
+
+
+def max_pool_grad(x, dy, stride=2):
+    b, h, w, c = x.shape
+    win, oh, ow = _pool_windows(x, stride)
+    arg = win.argmax(0)  # first max in scan order (dy-major, dx-minor)
+    dx_full = np.zeros((b, h + 1, w + 1, c), dtype=dy.dtype)
+    for k in range(4):
+        ky, kx = k // 2, k % 2
+        sel = np.where(arg == k, dy, dy.dtype.type(0))
+        dx_full[:, ky:ky + oh * stride:stride, kx:kx + ow * stride:stride, :] += sel
+    return dx_full[:, :h, :w, :]
+
+
+# --------------------------------------------------------------------------------------
+# network topology (restated from model/yolo2/inference.py; never imported from the product)
+# --------------------------------------------------------------------------------------
+
+def darknet_spec(classes, num_anchors):
+    """model/yolo2/inference.py:61-120.  Returns a list of ops:
+    ('conv', name, ksize, cout, bn) | ('pool', stride) | ('mark',) | ('reorg_concat',)."""
+    ops = []
+    idx = 0
+    ch = 32
+    for _ in range(2):  # :72-76
+        ops += [('conv', 'conv%d' % idx, 3, ch, True), ('pool', 2)]
+        idx += 1
+        ch *= 2
+    for _ in range(2):  # :77-85
+        ops += [('conv', 'conv%d' % idx, 3, ch, True)]
+        idx += 1
+        ops += [('conv', 'conv%d' % idx, 1, ch // 2, True)]
+        idx += 1
+        ops += [('conv', 'conv%d' % idx, 3, ch, True), ('pool', 2)]
+        idx += 1
+        ch *= 2
+    for k, c in ((3, ch), (1, ch // 2), (3, ch), (1, ch // 2), (3, ch)):  # :86-94
+        ops += [('conv', 'conv%d' % idx, k, c, True)]
+        idx += 1
+    ops += [('mark',), ('pool', 2)]  # passthrough :95, pool :96
+    ch *= 2
+    for k, c in ((3, ch), (1, ch // 2), (3, ch), (1, ch // 2), (3, ch), (3, ch), (3, ch)):  # :100-112
+        ops += [('conv', 'conv%d' % idx, k, c, True)]
+        idx += 1
+    ops += [('reorg_concat',)]  # :114-116, reorg output first
+    ops += [('conv', 'conv%d' % idx, 3, ch, True)]  # :117
+    ops += [('conv', 'conv', 1, num_anchors * (5 + classes), False)]  # :118
+    return ops
+
+
+def tiny_spec(classes, num_anchors):
+    """model/yolo2/inference.py:25-50."""
+    ops = []
+    idx = 0
+    ch = 16
+    for _ in range(5):  # :36-40
+        ops += [('conv', 'conv%d' % idx, 3, ch, True), ('pool', 2)]
+        idx += 1
+        ch *= 2
+    ops += [('conv', 'conv%d' % idx, 3, ch, True), ('pool', 1)]  # :41-42
+    idx += 1
+    ch *= 2
+    ops += [('conv', 'conv%d' % idx, 3, ch, True)]  # :45
+    idx += 1
+    ops += [('conv', 'conv%d' % idx, 3, ch, True)]  # :47
+    ops += [('conv', 'conv', 1, num_anchors * (5 + classes), False)]  # :48
+    return ops
+
+
+SPECS = {'darknet': darknet_spec, 'tiny': tiny_spec}
+
+
+def init_params(spec, cin=3, seed=0, dtype=np.float32, tiny=False):
+    """[TF-sem] slim conv2d default init: Xavier-uniform weights (tiny: truncated normal 0.1,
+    model/yolo2/inference.py:33), gamma=1 beta=0 moving_mean=0 moving_variance=1, biases=0."""
+    rng = np.random.RandomState(seed)
+    params = {}
+    c = cin
+    mark_c = None
+    for op in spec:
+        if op[0] == 'conv':
+            _, name, k, cout, bn = op
+            if tiny and bn:
+                w = np.clip(rng.randn(k, k, c, cout), -2, 2) * 0.1
+            else:
+                lim = np.sqrt(6.0 / (k * k * c + k * k * cout))
+                w = rng.uniform(-lim, lim, size=(k, k, c, cout))
+            params[name + '/weights'] = w.astype(dtype)
+            if bn:
+                params[name + '/BatchNorm/gamma'] = np.ones(cout, dtype)
+                params[name + '/BatchNorm/beta'] = np.zeros(cout, dtype)
+                params[name + '/BatchNorm/moving_mean'] = np.zeros(cout, dtype)
+                params[name + '/BatchNorm/moving_variance'] = np.ones(cout, dtype)
+            else:
+                params[name + '/biases'] = np.zeros(cout, dtype)
+            c = cout
+        elif op[0] == 'mark':
+            mark_c = c
+        elif op[0] == 'reorg_concat':
+            c = mark_c * 4 + c
+    return params
+
+
+def trainable_names(params):
+    return [k for k in params if not k.endswith(('moving_mean', 'moving_variance'))]
+
+
+def network_forward(spec, params, x, training):
+    """Runs the op list; returns (net, caches).  Training uses batch statistics and returns
+    the moving-average updates in caches['ema'] ([TF-sem] UPDATE_OPS run by create_train_op)."""
+    caches = []
+    ema = {}
+    net = x
+    mark = None
+    for op in spec:
+        if op[0] == 'conv':
+            _, name, k, cout, bn = op
+            w = params[name + '/weights']
+            y = conv2d(net, w)
+            if bn:
+                g = params[name + '/BatchNorm/gamma']
+                bt = params[name + '/BatchNorm/beta']
+                if training:
+                    mean, var = bn_moments(y)
+                    ema[name + '/BatchNorm/moving_mean'] = bn_ema(params[name + '/BatchNorm/moving_mean'], mean)
+                    ema[name + '/BatchNorm/moving_variance'] = bn_ema(params[name + '/BatchNorm/moving_variance'], var)
+                else:
+                    mean = params[name + '/BatchNorm/moving_mean']
+                    var = params[name + '/BatchNorm/moving_variance']
+                z = bn_apply(y, mean, var, g, bt)
+                out = leaky_relu(z)
+                caches.append(('conv', name, net, y, mean, var, z))
+            else:
+                out = y + params[name + '/biases']
+                caches.append(('conv', name, net, None, None, None, None))
+            net = out
+        elif op[0] == 'pool':
+            caches.append(('pool', op[1], net))
+            net = max_pool(net, op[1])
+        elif op[0] == 'mark':
+            mark = net
+            caches.append(('mark',))
+        elif op[0] == 'reorg_concat':
+            r = reorg(mark)
+            caches.append(('reorg_concat', r.shape[-1]))
+            net = np.concatenate([r, net], axis=3)
+    return net, {'ops': caches, 'ema': ema}
+
+
+def network_backward(spec, params, caches, dnet):
+    """Reverse sweep; returns gradients for every trainable variable."""
+    grads = {}
+    dmark = None
+    for op, cache in zip(reversed(spec), reversed(caches['ops'])):
+        if op[0] == 'conv':
+            _, name, k, cout, bn = op
+            _, _, xin, y, mean, var, z = cache
+            w = params[name + '/weights']
+            if bn:
+                dz = leaky_relu_grad(z, dnet)
+                dy, dg, db = bn_train_bwd(y, mean, var, params[name + '/BatchNorm/gamma'], dz)
+                grads[name + '/BatchNorm/gamma'] = dg
+                grads[name + '/BatchNorm/beta'] = db
+            else:
+                dy = dnet
+                grads[name + '/biases'] = dy.reshape(-1, cout).astype(np.float64).sum(0).astype(dy.dtype)
+            grads[name + '/weights'] = conv2d_wgrad(xin, dy, k, k)
+            dnet = conv2d_dgrad(dy, w)
+        elif op[0] == 'pool':
+            dnet = max_pool_grad(cache[2], dnet, cache[1])
+        elif op[0] == 'mark':
+            dnet = dnet + dmark
+        elif op[0] == 'reorg_concat':
+            cr = cache[1]
+            dmark = reorg_grad(dnet[..., :cr])
+            dnet = dnet[..., cr:]
+    return grads
+
+
+# --------------------------------------------------------------------------------------
+# decode head and loss (model/yolo2/__init__.py:28-94, model/yolo/__init__.py:29-34)
+# --------------------------------------------------------------------------------------
+
+def calc_cell_xy(cell_height, cell_width, dtype=np.float32):
+    """model/yolo/__init__.py:29-34 -- cell_base[y,x,:] = [x,y]."""
+    ys, xs = np.meshgrid(np.arange(cell_height), np.arange(cell_width), indexing='ij')
+    return np.stack([xs, ys], -1).astype(dtype)
+
+
+def sigmoid(x):
+    return x.dtype.type(1) / (x.dtype.type(1) + np.exp(-x))
+
+
+def softmax(x):
+    e = np.exp(x - x.max(-1, keepdims=True))
+    return e / e.sum(-1, keepdims=True)
+
+
+def model_decode(net, classes, anchors, training=False):
+    """model/yolo2/__init__.py:28-59.  net [B,ch,cw,A*(5+C)], anchors [A,2] (w,h) in cells."""
+    t = net.dtype.type
+    b, ch, cw, _ = net.shape
+    cells = ch * cw
+    a = len(anchors)
+    anchors = np.asarray(anchors, net.dtype)
+    inputs = net.reshape(b, cells, a, 5 + classes)                      # :32
+    sig = sigmoid(inputs[..., :3])                                       # :36
+    m = {'cell_width': cw, 'cell_height': ch, 'inputs': inputs}
+    m['iou'] = sig[..., 0]                                               # :37
+    m['offset_xy'] = sig[..., 1:3]                                       # :38
+    m['wh'] = np.exp(inputs[..., 3:5]) * anchors.reshape(1, 1, a, 2)     # :40
+    m['prob'] = softmax(inputs[..., 5:])                                 # :42
+    m['areas'] = m['wh'][..., 0] * m['wh'][..., 1]                       # :43
+    half = m['wh'] / t(2)                                                # :44
+    m['offset_xy_min'] = m['offset_xy'] - half                           # :45
+    m['offset_xy_max'] = m['offset_xy'] + half                           # :46
+    m['wh01'] = m['wh'] / np.array([cw, ch], net.dtype).reshape(1, 1, 1, 2)  # :47
+    m['wh01_sqrt'] = np.sqrt(m['wh01'])                                  # :48
+    m['coords'] = np.concatenate([m['offset_xy'], m['wh01_sqrt']], -1)   # :49
+    if not training:                                                     # :50-56
+        cell_xy = calc_cell_xy(ch, cw, net.dtype).reshape(1, cells, 1, 2)
+        m['xy'] = cell_xy + m['offset_xy']
+        m['xy_min'] = cell_xy + m['offset_xy_min']
+        m['xy_max'] = cell_xy + m['offset_xy_max']
+        m['conf'] = m['iou'][..., None] * m['prob']
+    return m
+
+
+OBJECTIVE_KEYS = ('iou_best', 'iou_normal', 'coords', 'prob')   # dict insertion order :90-94
+
+
+def objectives(m, labels):
+    """model/yolo2/__init__.py:62-94.  labels = (mask[B,cells,1], prob[B,cells,1,C],
+    coords[B,cells,1,4], offset_xy_min[B,cells,1,2], offset_xy_max[B,cells,1,2], areas[B,cells,1]).
+    Returns (dict of 4 scalars, aux dict with mask_best etc.)."""
+    mask, prob, coords, oxy_min, oxy_max, areas = labels
+    t = m['iou'].dtype.type
+    _min = np.maximum(m['offset_xy_min'], oxy_min)                       # :73
+    _max = np.minimum(m['offset_xy_max'], oxy_max)                       # :74
+    _wh = np.maximum(_max - _min, t(0))                                  # :75
+    _areas = _wh[..., 0] * _wh[..., 1]                                   # :76
+    union = np.maximum(areas + m['areas'] - _areas, t(1e-10))            # :77
+    iou = _areas / union                                                 # :78
+    best_iou = iou.max(2, keepdims=True)                                 # :80
+    best_box = (iou == best_iou).astype(iou.dtype)                       # :81 exact equality
+    mask_best = mask * best_box                                          # :82
+    mask_normal = t(1) - mask_best                                       # :83
+    iou_dist = (m['iou'] - mask_best) ** 2                               # :85
+    coords_dist = (m['coords'] - coords) ** 2                            # :86
+    prob_dist = (m['prob'] - prob) ** 2                                  # :87
+    cnt = t(iou_dist.size)                                               # :89 static shape product
+    mb = mask_best[..., None]
+    obj = {
+        'iou_best': (mask_best * iou_dist).sum(dtype=np.float64) / cnt,
+        'iou_normal': (mask_normal * iou_dist).sum(dtype=np.float64) / cnt,
+        'coords': (mb * coords_dist).sum(dtype=np.float64) / cnt,
+        'prob': (mb * prob_dist).sum(dtype=np.float64) / cnt,
+    }
+    obj = {k: t(v) for k, v in obj.items()}
+    return obj, {'mask_best': mask_best, 'iou': iou, 'cnt': cnt}
+
+
+def total_loss(obj, hparam):
+    """train.py:113 tf.losses.get_total_loss = sum of weighted objectives
+    (model/yolo2/__init__.py:117-119); yolo2 adds no regularisers."""
+    return sum(obj[k] * type(obj[k])(hparam[k]) for k in OBJECTIVE_KEYS)
+
+
+def loss_backward(m, labels, aux, hparam, classes):
+    """d total_loss / d net, derived from model/yolo2/__init__.py:36-49,85-94.  The IoU feeds
+    only tf.equal (:81), so no gradient flows through it."""
+    mask, prob_t, coords_t, _, _, _ = labels
+    t = m['iou'].dtype.type
+    mb = aux['mask_best']
+    cnt = aux['cnt']
+    two = t(2)
+    b, cells, a = m['iou'].shape
+    dz = np.zeros((b, cells, a, 5 + classes), dtype=m['iou'].dtype)
+    s = m['iou']
+    w_obj = t(hparam['iou_best']) * mb + t(hparam['iou_normal']) * (t(1) - mb)
+    dz[..., 0] = two * (s - mb) * w_obj / cnt * s * (t(1) - s)
+    sxy = m['offset_xy']
+    dz[..., 1:3] = two * mb[..., None] * (sxy - coords_t[..., :2]) * t(hparam['coords']) / cnt * sxy * (t(1) - sxy)
+    sq = m['wh01_sqrt']
+    dz[..., 3:5] = two * mb[..., None] * (sq - coords_t[..., 2:4]) * t(hparam['coords']) / cnt * sq / two
+    p = m['prob']
+    d = two * mb[..., None] * (p - prob_t) * t(hparam['prob']) / cnt
+    dz[..., 5:] = p * (d - (d * p).sum(-1, keepdims=True))
+    return dz.reshape(b, m['cell_height'], m['cell_width'], a * (5 + classes))
+
+
+# --------------------------------------------------------------------------------------
+# optimizers (train.py:70-80) and learning-rate schedule (train.py:116-124, config.ini:30-33)
+# --------------------------------------------------------------------------------------
+
+def exponential_decay(lr, global_step, decay_steps, decay_rate, staircase):
+    p = global_step / decay_steps
+    if staircase:
+        p = np.floor(p)
+    return lr * decay_rate ** p
+
+
+def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
+    """[TF-sem] tf.train.AdamOptimizer (ApplyAdam kernel): alpha = lr*sqrt(1-b2^t)/(1-b1^t);
+    m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= alpha*m/(sqrt(v)+eps)  (eps outside the sqrt)."""
+    ty = w.dtype.type
+    alpha = ty(lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t))
+    m = m + (g - m) * ty(1 - beta1)
+    v = v + (g * g - v) * ty(1 - beta2)
+    w = w - (m * alpha) / (np.sqrt(v) + ty(eps))
+    return w, m, v
+
+
+def momentum_step(w, g, acc, lr, momentum=0.9):
+    """[TF-sem] ApplyMomentum (no nesterov): acc = acc*momentum + g; w -= lr*acc."""
+    ty = w.dtype.type
+    acc = acc * ty(momentum) + g
+    return w - ty(lr) * acc, acc
+
+
+def gd_step(w, g, lr):
+    return w - w.dtype.type(lr) * g
+
+
+def rmsprop_step(w, g, ms, mom, lr, decay=0.9, momentum=0.0, eps=1e-10):
+    """[TF-sem] ApplyRMSProp: ms += (g^2-ms)(1-decay); mom = mom*momentum + lr*g/sqrt(ms+eps); w -= mom."""
+    ty = w.dtype.type
+    ms = ms + (g * g - ms) * ty(1 - decay)
+    mom = mom * ty(momentum) + ty(lr) * g / np.sqrt(ms + ty(eps))
+    return w - mom, ms, mom
+
+
+def adagrad_step(w, g, acc, lr):
+    """[TF-sem] ApplyAdagrad: acc += g^2; w -= lr*g/sqrt(acc)."""
+    acc = acc + g * g
+    return w - w.dtype.type(lr) * g / np.sqrt(acc), acc
+
+
+def adadelta_step(w, g, acc, acc_update, lr, rho=0.95, eps=1e-8):
+    """[TF-sem] ApplyAdadelta: acc = rho*acc+(1-rho)g^2; upd = sqrt(acc_update+eps)/sqrt(acc+eps)*g;
+    acc_update = rho*acc_update+(1-rho)upd^2; w -= lr*upd."""
+    ty = w.dtype.type
+    acc = acc * ty(rho) + g * g * ty(1 - rho)
+    upd = np.sqrt(acc_update + ty(eps)) / np.sqrt(acc + ty(eps)) * g
+    acc_update = acc_update * ty(rho) + upd * upd * ty(1 - rho)
+    return w - ty(lr) * upd, acc, acc_update
+
+
+def clip_by_norm(g, clip):
+    """[TF-sem] slim create_train_op clip_gradient_norm -> per-tensor tf.clip_by_norm."""
+    n = np.sqrt((g.astype(np.float64) ** 2).sum())
+    return g * g.dtype.type(clip / max(n, clip)) if clip > 0 else g
+
+
+# --------------------------------------------------------------------------------------
+# detect-side helpers
+# --------------------------------------------------------------------------------------
+
+def per_image_standardization(image):
+    """utils/preprocess.py:23-25 (== [TF-sem] tf.image.per_image_standardization, train.py:103):
+    (x-mean)/max(std, 1/sqrt(N)), population std over the whole image."""
+    stddev = np.std(image)
+    return (image - np.mean(image)) / max(stddev, 1.0 / np.sqrt(np.multiply.reduce(image.shape)))
+
+
+def iou(xy_min1, xy_max1, xy_min2, xy_max2):
+    """utils/postprocess.py:21-36, fp32 op order (a1+a2)-inter, floor 1e-10."""
+    areas1 = np.multiply.reduce(xy_max1 - xy_min1)
+    areas2 = np.multiply.reduce(xy_max2 - xy_min2)
+    _xy_min = np.maximum(xy_min1, xy_min2)
+    _xy_max = np.minimum(xy_max1, xy_max2)
+    _wh = np.maximum(_xy_max - _xy_min, 0)
+    _areas = np.multiply.reduce(_wh)
+    return _areas / np.maximum(areas1 + areas2 - _areas, 1e-10)
+
+
+def non_max_suppress(conf, xy_min, xy_max, threshold, threshold_iou):
+    """utils/postprocess.py:39-51 restated with explicit indices instead of a list of views.
+    Mutates ``conf`` in place; returns ``order`` (box indices in the order the reference's
+    returned list has, i.e. after the last class's stable sort)."""
+    cells, a, classes = conf.shape
+    n = cells * a
+    cf = conf.reshape(n, classes)
+    mn = xy_min.reshape(n, 2)
+    mx = xy_max.reshape(n, 2)
+    order = list(range(n))
+    for c in range(classes):
+        order.sort(key=lambda i: cf[i, c], reverse=True)          # :43 stable, carried order
+        for p in range(n - 1):                                     # :44
+            i = order[p]
+            if cf[i, c] <= threshold:                              # :46-47
+                continue
+            for j in order[p + 1:]:                                # :48
+                if iou(mn[i], mx[i], mn[j], mx[j]) >= threshold_iou:   # :49
+                    cf[j, c] = 0                                   # :50
+    return np.asarray(order, dtype=np.int64)
+
+
+def non_max_suppress_fast(conf, xy_min, xy_max, threshold, threshold_iou):
+    """Vectorised restatement of the same algorithm (identical fp32 arithmetic per pair, same
+    carried stable order); used where the pure-Python loop above is too slow.  Checked against
+    :func:`non_max_suppress` and the reference goldens in tests/test_oracle.py."""
+    cells, a, classes = conf.shape
+    n = cells * a
+    cf = conf.reshape(n, classes)
+    mn = xy_min.reshape(n, 2).astype(np.float32)
+    mx = xy_max.reshape(n, 2).astype(np.float32)
+    thr = np.float32(threshold)
+    thr_iou = np.float32(threshold_iou)
+    wh = mx - mn
+    area = wh[:, 0] * wh[:, 1]
+    order = np.arange(n)
+    for c in range(classes):
+        key = cf[order, c]
+        order = order[np.argsort(-key, kind='stable')]   # stable descending, ties keep carried order (:43)
+        col = cf[:, c]
+        for p in range(n - 1):
+            i = order[p]
+            if col[i] <= thr:
+                continue
+            rest = order[p + 1:]
+            _min = np.maximum(mn[i], mn[rest])
+            _max = np.minimum(mx[i], mx[rest])
+            _wh = np.maximum(_max - _min, np.float32(0))
+            inter = _wh[:, 0] * _wh[:, 1]
+            v = inter / np.maximum((area[i] + area[rest]) - inter, np.float32(1e-10))
+            col[rest[v >= thr_iou]] = 0
+    return order.astype(np.int64)
+
+
+def transform_labels(objects_class, objects_coord, classes, cell_width, cell_height, dtype=np.float32):
+    """utils/data/__init__.py:112-145.  coords normalised (xmin,ymin,xmax,ymax) in [0,1]."""
+    cells = cell_height * cell_width
+    mask = np.zeros([cells, 1], dtype=dtype)
+    prob = np.zeros([cells, 1, classes], dtype=dtype)
+    coords = np.zeros([cells, 1, 4], dtype=dtype)
+    offset_xy_min = np.zeros([cells, 1, 2], dtype=dtype)
+    offset_xy_max = np.zeros([cells, 1, 2], dtype=dtype)
+    objects_class = np.asarray(objects_class)
+    objects_coord = np.asarray(objects_coord)
+    if len(objects_class):
+        xmin, ymin, xmax, ymax = objects_coord.T
+        x = cell_width * (xmin + xmax) / 2                         # :121
+        y = cell_height * (ymin + ymax) / 2
+        ix, iy = np.floor(x), np.floor(y)
+        ox, oy = x - ix, y - iy
+        w, h = xmax - xmin, ymax - ymin
+        index = (iy * cell_width + ix).astype(int)                 # :129
+        mask[index, :] = 1
+        prob[index, :, objects_class] = 1                          # multi-hot if a cell is shared
+        coords[index, 0, 0] = ox
+        coords[index, 0, 1] = oy
+        coords[index, 0, 2] = np.sqrt(w)
+        coords[index, 0, 3] = np.sqrt(h)
+        _w, _h = w / 2 * cell_width, h / 2 * cell_height
+        offset_xy_min[index, 0, 0] = ox - _w
+        offset_xy_min[index, 0, 1] = oy - _h
+        offset_xy_max[index, 0, 0] = ox + _w
+        offset_xy_max[index, 0, 1] = oy + _h
+    wh = offset_xy_max - offset_xy_min
+    areas = np.multiply.reduce(wh, -1)
+    return mask, prob, coords, offset_xy_min, offset_xy_max, areas
+
+
+# --------------------------------------------------------------------------------------
+# one full training step / detect pass (callers train.py:109-129, detect.py:69-71)
+# --------------------------------------------------------------------------------------
+
+def train_step(spec, params, opt_state, x, labels, classes, anchors, hparam, lr, step,
+               adam=(0.9, 0.999, 1e-8)):
+    """Forward (batch-stat BN) + loss + backward + Adam; returns (new_params, new_state, info).
+    ``step`` counts completed updates (Adam's t = step+1)."""
+    net, caches = network_forward(spec, params, x, training=True)
+    m = model_decode(net, classes, anchors, training=True)
+    obj, aux = objectives(m, labels)
+    loss = total_loss(obj, hparam)
+    dnet = loss_backward(m, labels, aux, hparam, classes)
+    grads = network_backward(spec, params, caches, dnet)
+    new_params = dict(params)
+    new_params.update(caches['ema'])                     # UPDATE_OPS before the step [TF-sem]
+    new_state = {}
+    for k in trainable_names(params):
+        mm, vv = opt_state.get(k, (np.zeros_like(params[k]), np.zeros_like(params[k])))
+        w, mm, vv = adam_step(params[k], grads[k], mm, vv, lr, step + 1, *adam)
+        new_params[k] = w
+        new_state[k] = (mm, vv)
+    return new_params, new_state, {'loss': loss, 'objectives': obj, 'grads': grads, 'net': net}
+
+
+def detect(spec, params, x, classes, anchors, threshold=0.3, threshold_iou=0.4):
+    """detect.py:69-80 for a batch: forward (moving-stat BN) -> decode -> per-image NMS."""
+    net, _ = network_forward(spec, params, x, training=False)
+    m = model_decode(net, classes, anchors, training=False)
+    conf = m['conf'].copy()
+    orders = []
+    for b in range(conf.shape[0]):
+        orders.append(non_max_suppress_fast(conf[b], m['xy_min'][b], m['xy_max'][b], threshold, threshold_iou))
+    return conf, m['xy_min'], m['xy_max'], orders

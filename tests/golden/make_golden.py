@@ -1,0 +1,187 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own NumPy-only functions.
+
+Run once in the build container (needs /root/reference; TensorFlow is absent, so the
+``tensorflow`` import chain is stubbed and ``np.int`` -- removed from NumPy -- is shimmed):
+
+    python tests/golden/make_golden.py
+
+Only inputs and expected outputs are stored (data); no reference source travels with the repo.
+Reference functions exercised:
+    utils/postprocess.py:21-51      iou, non_max_suppress
+    utils/data/__init__.py:112-145  transform_labels
+    model/yolo/__init__.py:29-34    calc_cell_xy
+    utils/preprocess.py:23-25       per_image_standardization
+    model/yolo2/function.py:32-47   reorg known-answer image (the TF op itself cannot run; the
+                                    KAT's input and its asserted per-channel constants are stored)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub_tf():
+    names = ['tensorflow', 'tensorflow.python', 'tensorflow.python.client',
+             'tensorflow.python.client.device_lib', 'tensorflow.contrib', 'tensorflow.contrib.slim',
+             'matplotlib', 'matplotlib.patches', 'matplotlib.pyplot']
+    for n in names:
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules['tensorflow'].contrib = sys.modules['tensorflow.contrib']
+    sys.modules['tensorflow.contrib'].slim = sys.modules['tensorflow.contrib.slim']
+    sys.modules['tensorflow.python'].client = sys.modules['tensorflow.python.client']
+    sys.modules['tensorflow.python.client'].device_lib = sys.modules['tensorflow.python.client.device_lib']
+    sys.modules['matplotlib'].patches = sys.modules['matplotlib.patches']
+    if not hasattr(np, 'int'):
+        np.int = int
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def boxes_from(center, wh):
+    center = center.astype(np.float32)
+    wh = wh.astype(np.float32)
+    return (center - wh / 2).astype(np.float32), (center + wh / 2).astype(np.float32)
+
+
+def nms_case(post, name, conf, xy_min, xy_max, thr, thr_iou, cases):
+    conf_in = conf.copy()
+    n = conf.shape[0] * conf.shape[1]
+    tag = np.arange(n, dtype=np.float32)
+    # carry the original index through the reference's list by appending it to xy_min rows? No --
+    # the reference returns views; recover the order by matching row addresses instead.
+    work = conf.copy()
+    boxes = post.non_max_suppress(work, xy_min, xy_max, thr, thr_iou)
+    flat = work.reshape(n, -1)
+    base = flat.__array_interface__['data'][0]
+    stride = flat.strides[0]
+    order = np.array([(b[0].__array_interface__['data'][0] - base) // stride for b in boxes], np.int64)
+    assert sorted(order.tolist()) == list(range(n))
+    cases[name + '/conf_in'] = conf_in
+    cases[name + '/xy_min'] = xy_min
+    cases[name + '/xy_max'] = xy_max
+    cases[name + '/thr'] = np.float64(thr)
+    cases[name + '/thr_iou'] = np.float64(thr_iou)
+    cases[name + '/conf_out'] = work
+    cases[name + '/order'] = order
+    del tag
+
+
+def make_nms(post):
+    cases = {}
+    # 1. sparse realistic, 845 x 20 (BASELINE.md section 2 recipe)
+    for name, classes, seed in (('sparse20', 20, 1), ('sparse80', 80, 2)):
+        rng = np.random.RandomState(seed)
+        conf = rng.uniform(0, 0.05, (169, 5, classes)).astype(np.float32)
+        hot = rng.choice(845, 12, replace=False)
+        conf.reshape(845, classes)[hot, rng.randint(0, classes, 12)] = rng.uniform(0.5, 0.9, 12).astype(np.float32)
+        mn, mx = boxes_from(rng.uniform(0, 13, (169, 5, 2)), rng.uniform(0.5, 5.5, (169, 5, 2)))
+        nms_case(post, name, conf, mn, mx, 0.3, 0.4, cases)
+    # 2. dense random (small enough for the Python reference): 40 cells x 5 anchors x 6 classes
+    rng = np.random.RandomState(0)
+    conf = rng.uniform(0, 0.5, (40, 5, 6)).astype(np.float32)
+    mn, mx = boxes_from(rng.uniform(0, 13, (40, 5, 2)), rng.uniform(0, 4, (40, 5, 2)))
+    nms_case(post, 'dense', conf, mn, mx, 0.3, 0.4, cases)
+    # 3. clustered duplicates: 8 clusters of jittered boxes
+    rng = np.random.RandomState(3)
+    cen = np.repeat(rng.uniform(2, 11, (8, 2)), 20, 0) + rng.normal(0, 0.15, (160, 2))
+    wh = np.repeat(rng.uniform(1, 4, (8, 2)), 20, 0) * rng.uniform(0.9, 1.1, (160, 2))
+    mn, mx = boxes_from(cen.reshape(32, 5, 2), wh.reshape(32, 5, 2))
+    conf = rng.uniform(0, 1, (32, 5, 4)).astype(np.float32)
+    nms_case(post, 'clustered', conf, mn, mx, 0.3, 0.4, cases)
+    # 4. identical boxes (IoU == 1) and equal-score ties (stable order must carry across classes)
+    rng = np.random.RandomState(4)
+    mn, mx = boxes_from(np.tile(np.float32([[5, 5]]), (30, 1)).reshape(6, 5, 2), np.tile(np.float32([[2, 3]]), (30, 1)).reshape(6, 5, 2))
+    conf = rng.choice(np.float32([0.25, 0.5, 0.5, 0.75]), (6, 5, 3)).astype(np.float32)
+    nms_case(post, 'identical_ties', conf, mn, mx, 0.3, 0.4, cases)
+    # 5. ties with distinct geometry: scores drawn from 4 values, boxes random
+    rng = np.random.RandomState(5)
+    conf = rng.choice(np.float32([0.1, 0.35, 0.6, 0.6, 0.9]), (20, 5, 5)).astype(np.float32)
+    mn, mx = boxes_from(rng.uniform(0, 13, (20, 5, 2)), rng.uniform(1, 6, (20, 5, 2)))
+    nms_case(post, 'ties', conf, mn, mx, 0.3, 0.4, cases)
+    # 6. IoU exactly at threshold: unit squares offset so that IoU = 1/3 and 0.5 (>= must fire)
+    mn = np.float32([[0, 0], [0.5, 0], [4, 4], [4, 4.5], [8, 8]]).reshape(1, 5, 2)
+    mx = mn + np.float32(1)
+    conf = np.float32([[0.9], [0.8], [0.7], [0.6], [0.5]]).reshape(1, 5, 1)
+    iou_pair = post.iou(mn[0, 0], mx[0, 0], mn[0, 1], mx[0, 1])
+    nms_case(post, 'at_threshold', conf, mn, mx, 0.3, float(iou_pair), cases)
+    # 7. all below threshold -> no-op
+    rng = np.random.RandomState(7)
+    conf = rng.uniform(0, 0.29, (10, 5, 3)).astype(np.float32)
+    mn, mx = boxes_from(rng.uniform(0, 13, (10, 5, 2)), rng.uniform(1, 6, (10, 5, 2)))
+    nms_case(post, 'all_below', conf, mn, mx, 0.3, 0.4, cases)
+    # 8. zero-area boxes (union floor 1e-10) mixed with normal ones
+    rng = np.random.RandomState(8)
+    cen = rng.uniform(0, 13, (10, 5, 2))
+    wh = rng.uniform(0, 3, (10, 5, 2))
+    wh[::2, :, 0] = 0
+    mn, mx = boxes_from(cen, wh)
+    conf = rng.uniform(0, 1, (10, 5, 2)).astype(np.float32)
+    nms_case(post, 'zero_area', conf, mn, mx, 0.3, 0.4, cases)
+    # iou table
+    rng = np.random.RandomState(9)
+    a_mn, a_mx = boxes_from(rng.uniform(0, 13, (64, 2)), rng.uniform(0, 5, (64, 2)))
+    b_mn, b_mx = boxes_from(rng.uniform(0, 13, (64, 2)), rng.uniform(0, 5, (64, 2)))
+    cases['iou/a_min'], cases['iou/a_max'], cases['iou/b_min'], cases['iou/b_max'] = a_mn, a_mx, b_mn, b_mx
+    cases['iou/out'] = np.array([post.iou(a_mn[i], a_mx[i], b_mn[i], b_mx[i]) for i in range(64)], np.float32)
+    np.savez_compressed(os.path.join(OUT, 'nms.npz'), **cases)
+    print('nms.npz', len(cases), 'arrays')
+
+
+def make_labels(data_mod, yolo_mod, pre_mod):
+    cases = {}
+    for name, classes, cw, ch, k, seed in (('voc13', 20, 13, 13, 6, 0), ('coco13', 80, 13, 13, 9, 1),
+                                           ('rect', 20, 19, 10, 5, 2), ('shared_cell', 20, 13, 13, 4, 3)):
+        rng = np.random.RandomState(seed)
+        cen = rng.uniform(0.05, 0.95, (k, 2))
+        wh = rng.uniform(0.05, 0.6, (k, 2))
+        if name == 'shared_cell':
+            cen[1] = cen[0] + 0.001  # two objects in one cell -> multi-hot prob, last one wins elsewhere
+        coord = np.clip(np.concatenate([cen - wh / 2, cen + wh / 2], 1), 0, 1).astype(np.float32)
+        cls = rng.randint(0, classes, k).astype(np.int64)
+        out = data_mod.transform_labels(cls, coord, classes, cw, ch)
+        cases[name + '/class'] = cls
+        cases[name + '/coord'] = coord
+        cases[name + '/dims'] = np.array([classes, cw, ch], np.int64)
+        for key, v in zip(('mask', 'prob', 'coords', 'offset_xy_min', 'offset_xy_max', 'areas'), out):
+            cases[name + '/' + key] = v
+    cases['cell_xy/13x13'] = yolo_mod.calc_cell_xy(13, 13)
+    cases['cell_xy/10x19'] = yolo_mod.calc_cell_xy(10, 19)
+    rng = np.random.RandomState(11)
+    img = rng.uniform(0, 255, (32, 48, 3)).astype(np.float32)
+    cases['std/in'] = img
+    cases['std/out'] = pre_mod.per_image_standardization(img)
+    flat = np.full((8, 8, 3), 7, np.float32)
+    cases['std/flat_in'] = flat
+    cases['std/flat_out'] = pre_mod.per_image_standardization(flat)
+    # reorg KAT (model/yolo2/function.py:33-47): input image and the asserted channel constants
+    image = np.array([(0, 1, 0, 1), (2, 3, 2, 3), (0, 1, 0, 1), (2, 3, 2, 3)], np.uint8)[None, :, :, None]
+    cases['reorg/kat_in'] = image
+    cases['reorg/kat_channel_values'] = np.arange(4, dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, 'labels.npz'), **cases)
+    print('labels.npz', len(cases), 'arrays')
+
+
+def main():
+    _stub_tf()
+    sys.path.insert(0, REF)
+    post = _load('utils/postprocess.py', 'ref_postprocess')
+    pre = _load('utils/preprocess.py', 'ref_preprocess')
+    import utils.data as ref_data          # noqa: E402  (reference package, stubbed TF)
+    import model.yolo as ref_yolo          # noqa: E402
+    make_nms(post)
+    make_labels(ref_data, ref_yolo, pre)
+
+
+if __name__ == '__main__':
+    main()
