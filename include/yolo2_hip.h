@@ -1,0 +1,173 @@
+/* yolo2_hip.h -- C ABI of the MI355X (gfx950) YOLOv2 hot path.
+ *
+ * The reference (ruiminshen/yolo-tf) has no FFI layer: its hot path is Python calling
+ * TensorFlow-1.0 ops and NumPy.  This header is the boundary a maintainer would bind instead of
+ * those ops (ctypes stub in INTEGRATION.md).  Each entry names the reference call site it
+ * replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers unless marked host; the caller owns every buffer
+ *     (outputs and workspaces included); nothing is allocated or freed behind the ABI.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), re-entrant, and keeps no global state besides a thread-local error string.
+ *   - return value: 0 = OK, otherwise a YOLO2_E_* code; yolo2_last_error() describes it.
+ *   - activations are NHWC with an explicit pixel stride `ld*` (elements between consecutive
+ *     pixels, >= channel count, multiple of 8); lanes in [C, ld) are padding the kernels never
+ *     write and always read as zero (the caller zero-fills buffers once at allocation).
+ *   - dtype selects the storage/compute type of activations and prepared filters:
+ *     YOLO2_F32 (parity mode, f32 MFMA, exact fmaf chains) or YOLO2_BF16 (bf16 MFMA, f32
+ *     accumulate).  Parameters, statistics, gradients of parameters and optimizer state are
+ *     always f32.
+ */
+#ifndef YOLO2_HIP_H
+#define YOLO2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { YOLO2_F32 = 0, YOLO2_BF16 = 1 };
+enum {
+    YOLO2_OK = 0,
+    YOLO2_E_ARG = 1,      /* bad shape / alignment / enum */
+    YOLO2_E_LAUNCH = 2,   /* HIP launch or runtime error */
+    YOLO2_E_UNSUPPORTED = 3
+};
+
+int yolo2_abi_version(void);
+const char *yolo2_last_error(void);
+
+/* ---- convolution: slim.layers.conv2d, model/yolo2/inference.py:37-48,73-118 ------------------
+ * Implicit-GEMM NHWC convolution, stride 1, SAME zero padding, ksize 1 or 3:
+ *   O[b,h,w,n] = bias[n] + sum_{r,s,c<Cp} P[b,h+r-pad,w+s-pad,c] * F[n][(r*ksize+s)*Cp + c]
+ * P: [B,H,W,ldp] (dtype), F: [Nf][ksize*ksize*Cp] (dtype, K-contiguous, from yolo2_filter_prep),
+ * O: [B,H,W,ldo] (dtype), bias: f32[Nf] or NULL.  Forward uses the OHWI filter; the data
+ * gradient is the same call with P = dY and the flipped/transposed filter. */
+int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O,
+                 int B, int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize,
+                 int dtype, void *stream);
+
+/* Filter gradient of the same convolution (tf.gradients of conv2d, train.py:127-129):
+ *   dW[r,s,c,n] += sum_{b,h,w} X[b,h+r-pad,w+s-pad,c] * dY[b,h,w,n]       (HWIO, f32)
+ * dW must be zeroed by the caller: pixel-range splits accumulate with f32 atomics. */
+int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW,
+                       int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int ksize,
+                       int dtype, void *stream);
+
+/* HWIO f32 master weights [k,k,Cin,Cout] -> the two K-contiguous operand layouts:
+ *   Ffwd [Cout][k*k*ldcin]  : Ffwd[n][(r*k+s)*ldcin + c]      = W[r,s,c,n]
+ *   Fdgr [Cin ][k*k*ldcout] : Fdgr[c][(r*k+s)*ldcout + n]     = W[k-1-r,k-1-s,c,n]
+ * (zero in the padding lanes).  Either output may be NULL. */
+int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin, int ldcin,
+                      int Cout, int ldcout, int dtype, void *stream);
+
+/* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
+ * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
+/* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 2*C doubles (any content) */
+int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C,
+                   int dtype, void *stream);
+/* moving -= (1-decay)*(moving-batch)   (assign_moving_average, decay 0.999) */
+int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var,
+                 int C, float decay, void *stream);
+/* A[m,c] = leaky(gamma*(Y-mean)/sqrt(var+eps)+beta); A has pixel stride lda (concat target) */
+int yolo2_bn_leaky(const void *Y, const float *mean, const float *var, const float *gamma,
+                   const float *beta, void *A, long M, int C, int lda, float eps, float alpha,
+                   int dtype, void *stream);
+/* backward, pass 1: dgamma[c] = sum g*xhat, dbeta[c] = sum g with g = dA * leaky'(z);
+ * ws: >= 2*C doubles */
+int yolo2_bn_leaky_bwd_reduce(const void *dA, int ldda, const void *Y, const float *mean,
+                              const float *var, const float *gamma, const float *beta,
+                              float *dgamma, float *dbeta, double *ws, long M, int C,
+                              float eps, float alpha, int dtype, void *stream);
+/* backward, pass 2: dY = gamma*inv*(g - dbeta/M - xhat*dgamma/M) */
+int yolo2_bn_leaky_bwd_apply(const void *dA, int ldda, const void *Y, const float *mean,
+                             const float *var, const float *gamma, const float *beta,
+                             const float *dgamma, const float *dbeta, void *dY, long M, int C,
+                             float eps, float alpha, int dtype, void *stream);
+
+/* ---- max pool 2x2, SAME: slim.layers.max_pool2d, model/yolo2/inference.py:38,42,74,83,96 ------
+ * stride 2 (H,W even) or stride 1 (pads bottom/right; tiny model).  Backward routes to the
+ * first maximum in row-major window order. */
+int yolo2_maxpool_fwd(const void *A, void *P, int B, int H, int W, int C, int stride,
+                      int dtype, void *stream);
+int yolo2_maxpool_bwd(const void *A, const void *dP, void *dA, int B, int H, int W, int C,
+                      int stride, int dtype, void *stream);
+
+/* ---- reorg / concat: model/yolo2/function.py:22-29, model/yolo2/inference.py:114-116 ----------
+ * out[b,y,x,(sy*2+sx)*C+c] = in[b,2y+sy,2x+sx,c]; `out` has pixel stride ldo so it can be the
+ * leading channels of the concat buffer.  yolo2_reorg_bwd is the inverse move. */
+int yolo2_reorg(const void *in, void *out, int B, int H, int W, int C, int ldo, int dtype,
+                void *stream);
+int yolo2_reorg_bwd(const void *dout, int ldd, void *din, int B, int H, int W, int C, int dtype,
+                    void *stream);
+/* dst[m, 0:C] = src[m, 0:C] with independent pixel strides (tf.concat second operand / slice) */
+int yolo2_copy_channels(const void *src, int lds, void *dst, int ldd, long M, int C, int dtype,
+                        void *stream);
+/* dst += src elementwise over n elements (passthrough gradient join) */
+int yolo2_add_inplace(void *dst, const void *src, long n, int dtype, void *stream);
+/* dbias[c] = sum_m dY[m,c]  (final conv biases, model/yolo2/inference.py:118); ws >= C doubles */
+int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, int C, int dtype,
+                    void *stream);
+
+/* ---- input: tf.image.per_image_standardization train.py:103 / utils/preprocess.py:23-25 --------
+ * img: f32 [B,H,W,3] (0..255); out: dtype [B,H,W,8] (channels 3..7 zero).
+ * mode 0: (x-mean)/max(std,1/sqrt(N)) per image; mode 1: x/255 (detect.py:37-38);
+ * mode 2: plain cast.  ws: >= 2*B doubles. */
+int yolo2_image_prep(const float *img, void *out, double *ws, int B, int HW, int mode, int dtype,
+                     void *stream);
+
+/* ---- head decode: Model.__init__, model/yolo2/__init__.py:28-59 (detection block :50-56) ------
+ * logits [B,cells,ld] (channel order per anchor: iou,x,y,w,h,cls...), anchors f32[A][2] (w,h).
+ * Outputs f32: conf [B,cells,A,C], xy_min/xy_max [B,cells,A,2]; nan_flag (int, device) is set
+ * non-zero if any output is NaN/Inf (tf.check_numerics, detect.py:70). */
+int yolo2_head_decode(const void *logits, int ld, const float *anchors, float *conf,
+                      float *xy_min, float *xy_max, int *nan_flag, int B, int cell_h, int cell_w,
+                      int A, int C, int dtype, void *stream);
+
+/* ---- loss forward+backward: Objectives, model/yolo2/__init__.py:62-94 + Builder :114-119 -----
+ * labels (f32): mask[B,cells], prob[B,cells,C], coords[B,cells,4], off_min/off_max[B,cells,2],
+ * areas[B,cells].  hparam = HOST pointer to the 4 weights {iou_best, iou_normal, coords, prob}.
+ * objectives (f32[4], same order) receives the UNWEIGHTED sums / cnt, cnt = B*cells*A.
+ * dlogits (dtype, [B,cells,ld], may be NULL) receives d(total weighted loss)/d logits, padding
+ * lanes zeroed.  ws: >= 4*ceil(B*cells*L/256) floats, L = smallest power of two >= A. */
+int yolo2_loss(const void *logits, int ld, const float *anchors, const float *mask,
+               const float *prob, const float *coords, const float *off_min, const float *off_max,
+               const float *areas, const float *hparam, float *objectives, void *dlogits,
+               float *ws, int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream);
+
+/* ---- NMS: utils/postprocess.py:39-51 (iou :21-36), batched over images -----------------------
+ * conf [B,N,C] f32 is updated in place exactly as the reference mutates it; order_out [B,N]
+ * (int, may be NULL) receives per image the box indices in the order of the reference's
+ * returned list (stable descending sort by the last class, ties carried from earlier classes).
+ * ws: >= B*C*N ints. */
+int yolo2_nms(float *conf, const float *xy_min, const float *xy_max, int *order_out, int *ws,
+              int B, int N, int C, float threshold, float threshold_iou, void *stream);
+
+/* ---- optimizers: train.py:70-80 (TF-1.0 Apply* kernels), flat f32 buffers of n elements ------ */
+int yolo2_adam(float *w, const float *g, float *m, float *v, long n, float alpha, float beta1,
+               float beta2, float eps, float gscale, void *stream);   /* alpha = lr*sqrt(1-b2^t)/(1-b1^t) */
+int yolo2_momentum(float *w, const float *g, float *acc, long n, float lr, float momentum,
+                   float gscale, void *stream);
+int yolo2_sgd(float *w, const float *g, long n, float lr, float gscale, void *stream);
+int yolo2_rmsprop(float *w, const float *g, float *ms, float *mom, long n, float lr, float decay,
+                  float momentum, float eps, float gscale, void *stream);
+int yolo2_adagrad(float *w, const float *g, float *acc, long n, float lr, float gscale,
+                  void *stream);
+int yolo2_adadelta(float *w, const float *g, float *acc, float *acc_update, long n, float lr,
+                   float rho, float eps, float gscale, void *stream);
+/* per-tensor tf.clip_by_norm (slim create_train_op clip_gradient_norm, train.py:127-129):
+ * seg_off int64[nseg+1] element offsets into g; ws >= nseg doubles */
+int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, double *ws,
+                       void *stream);
+
+/* ---- diagnostics -----------------------------------------------------------------------------
+ * fills out[64*4] with the raw result of ds_read_b64_tr_b16 over a 0..N ramp (layout self-test) */
+int yolo2_selftest_tr16(short *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO2_HIP_H */

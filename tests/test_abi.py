@@ -1,0 +1,50 @@
+"""CPU-side boundary checks: the C-ABI library builds for gfx950, loads, and exports every symbol
+include/yolo2_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'yolo2_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(yolo2_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from yolo_tf_amd.csrc import build
+    path = build.build(verbose=False)
+    lib = ctypes.CDLL(path)
+    names = _declared()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(lib, n), 'missing symbol %s' % n
+    lib.yolo2_abi_version.restype = ctypes.c_int
+    assert lib.yolo2_abi_version() == 1
+
+
+def test_binding_table_matches_header():
+    from yolo_tf_amd import _lib
+    declared = set(_declared()) - {'yolo2_abi_version', 'yolo2_last_error'}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    _lib.load()
+
+
+def test_argument_errors_raise_without_touching_the_gpu():
+    import pytest
+    from yolo_tf_amd import _lib
+    with pytest.raises(_lib.HipKernelError, match='argument check failed'):
+        _lib.call('yolo2_conv2d', None, None, None, None, 1, 1, 1, 8, 8, 8, 8, 3, 0, None)
+    with pytest.raises(_lib.HipKernelError):
+        _lib.call('yolo2_nms', None, None, None, None, None, 1, 10, 2, 0.3, 0.4, None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    import pytest
+    from yolo_tf_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libyolo2hip.so')
+    with pytest.raises(_lib.HipKernelError, match='no CPU fallback'):
+        _lib.load()

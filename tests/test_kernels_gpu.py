@@ -1,0 +1,489 @@
+"""Per-kernel parity: every C-ABI entry point vs the CPU oracle on the same seeded inputs.
+Bit-exact for moves / integer decisions (reorg, pool routing, NMS keep-sets, filter layouts);
+1e-4 relative for fp32 arithmetic (BASELINE.json north_star); bf16 mode is compared with the
+oracle run on the bf16-rounded inputs at a bf16-sized tolerance (stated per test)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo2_ref as R
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32_RTOL = 1e-4          # north_star: within 1e-4 rel for fp32 conv/loss
+BF16_RTOL = 2e-2         # bf16 storage (8 mantissa bits) of outputs + bf16 operands, relative to the output scale
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from yolo_tf_amd import ops as _ops
+    _ops._lib.load()
+    assert torch.cuda.is_available()
+    return _ops
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to('cuda').to(dtype).contiguous()
+
+
+def host(t):
+    return t.float().cpu().numpy()
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def assert_close(got, ref, rtol, what=''):
+    scale = np.abs(ref).max() + 1e-30
+    err = np.abs(got - ref).max()
+    assert err <= rtol * scale, '%s: max abs err %.3e vs scale %.3e (rel %.3e > %.1e)' % (what, err, scale, err / scale, rtol)
+
+
+def pad_channels(x, ld):
+    out = np.zeros(x.shape[:-1] + (ld,), x.dtype)
+    out[..., :x.shape[-1]] = x
+    return out
+
+
+def run_conv(ops, x, w, bias, tdtype, ldo=None):
+    """x NHWC (np), w HWIO (np): forward through filter_prep + conv2d; returns y NHWC np (Cout real channels)."""
+    B, H, W, Cin = x.shape
+    k, _, _, Cout = w.shape
+    ldp = ops.pad8(Cin)
+    ldo = ldo or ops.pad8(Cout)
+    xd = dev(pad_channels(x, ldp), tdtype)
+    F = torch.zeros(Cout * k * k * ldp, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, ldp, Cout, ops.pad8(Cout), tdtype)
+    O = torch.zeros(B * H * W * ldo, dtype=tdtype, device='cuda')
+    ops.conv2d(xd, F, None if bias is None else dev(bias), O, B, H, W, ldp, ldp, Cout, ldo, k)
+    torch.cuda.synchronize()
+    y = host(O).reshape(B, H, W, ldo)
+    assert np.all(y[..., Cout:] == 0), 'padding lanes must stay untouched'
+    return y[..., :Cout]
+
+
+CONV_SHAPES = [
+    # B, H, W, Cin, Cout, k
+    (2, 13, 13, 16, 40, 3),
+    (1, 26, 20, 3, 32, 3),      # conv0-like: 3 real channels in an 8-wide pixel stride, Cout tile 32
+    (2, 13, 13, 64, 125, 1),    # final 1x1 + bias, ragged Cout, padded ldo
+    (2, 26, 26, 64, 160, 3),    # two N tiles, M tail (1352 rows)
+    (1, 8, 8, 24, 64, 3),       # BN=64 tile, channel tail inside a K step
+    (3, 5, 7, 136, 72, 3),      # odd extents, several K steps per tap
+]
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_conv_forward(ops, shape, mode):
+    B, H, W, Cin, Cout, k = shape
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(B, H, W, Cin).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
+    bias = rng.randn(Cout).astype(np.float32) if k == 1 else None
+    if mode == 'bf16':
+        x, w = bf16_round(x), bf16_round(w)
+    ref = R.conv2d(x, w) + (0 if bias is None else bias)
+    got = run_conv(ops, x, w, bias, torch.float32 if mode == 'f32' else torch.bfloat16)
+    assert_close(got, ref, F32_RTOL if mode == 'f32' else BF16_RTOL, 'conv fwd %s %s' % (shape, mode))
+
+
+@pytest.mark.parametrize('shape', CONV_SHAPES)
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_conv_dgrad(ops, shape, mode):
+    B, H, W, Cin, Cout, k = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(sum(shape) + 1)
+    dy = rng.randn(B, H, W, Cout).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cout)).astype(np.float32)
+    if mode == 'bf16':
+        dy, w = bf16_round(dy), bf16_round(w)
+    ref = R.conv2d_dgrad(dy, w)
+    ldy, ldx = ops.pad8(Cout), ops.pad8(Cin)
+    dyd = dev(pad_channels(dy, ldy), tdtype)
+    F = torch.zeros(Cin * k * k * ldy, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), None, F, k, Cin, ldx, Cout, ldy, tdtype)
+    dx = torch.zeros(B * H * W * ldx, dtype=tdtype, device='cuda')
+    ops.conv2d(dyd, F, None, dx, B, H, W, ldy, ldy, Cin, ldx, k)
+    torch.cuda.synchronize()
+    got = host(dx).reshape(B, H, W, ldx)[..., :Cin]
+    assert_close(got, ref, F32_RTOL if mode == 'f32' else BF16_RTOL, 'conv dgrad %s %s' % (shape, mode))
+
+
+WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]
+
+
+@pytest.mark.parametrize('shape', WGRAD_SHAPES)
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'bf16_gather'])
+def test_conv_wgrad(ops, shape, mode):
+    B, H, W, Cin, Cout, k = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(sum(shape) + 2)
+    x = rng.randn(B, H, W, Cin).astype(np.float32)
+    dy = rng.randn(B, H, W, Cout).astype(np.float32)
+    if mode != 'f32':
+        x, dy = bf16_round(x), bf16_round(dy)
+    ref = R.conv2d_wgrad(x, dy, k, k)
+    ldx, ldy = ops.pad8(Cin), ops.pad8(Cout)
+    dW = torch.zeros(k * k * Cin * Cout, dtype=torch.float32, device='cuda')
+    ops.set_wgrad_variant(1 if mode == 'bf16_gather' else 0)
+    try:
+        ops.conv2d_wgrad(dev(pad_channels(x, ldx), tdtype), dev(pad_channels(dy, ldy), tdtype), dW, B, H, W, Cin, ldx, Cout, ldy, k)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_wgrad_variant(0)
+    got = host(dW).reshape(k, k, Cin, Cout)
+    # bf16 operands are exact products accumulated in f32: same tolerance class as f32
+    assert_close(got, ref, F32_RTOL if mode == 'f32' else 1e-3, 'conv wgrad %s %s' % (shape, mode))
+
+
+def test_tr16_layout(ops):
+    """ds_read_b64_tr_b16 over a ramp: lane l, element j must read lds[(l&15) + 16*j + 64*(l>>4)]."""
+    out = ops.selftest_tr16()
+    exp = np.array([[(l & 15) + 16 * j + 64 * (l >> 4) for j in range(4)] for l in range(64)])
+    assert np.array_equal(out, exp), 'unexpected transpose-read layout:\n%s' % out
+
+
+def test_filter_prep_exact(ops):
+    rng = np.random.RandomState(0)
+    k, Cin, Cout = 3, 5, 11
+    ldcin, ldcout = 8, 16
+    w = rng.randn(k, k, Cin, Cout).astype(np.float32)
+    Ff = torch.full((Cout * 9 * ldcin,), 7.0, dtype=torch.float32, device='cuda')
+    Fd = torch.full((Cin * 9 * ldcout,), 7.0, dtype=torch.float32, device='cuda')
+    ops.filter_prep(dev(w), Ff, Fd, k, Cin, ldcin, Cout, ldcout, torch.float32)
+    torch.cuda.synchronize()
+    ef = np.zeros((Cout, 9, ldcin), np.float32)
+    ef[:, :, :Cin] = w.reshape(9, Cin, Cout).transpose(2, 0, 1)
+    ed = np.zeros((Cin, 9, ldcout), np.float32)
+    ed[:, :, :Cout] = w[::-1, ::-1].reshape(9, Cin, Cout).transpose(1, 0, 2)
+    assert np.array_equal(host(Ff).reshape(Cout, 9, ldcin), ef)
+    assert np.array_equal(host(Fd).reshape(Cin, 9, ldcout), ed)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 26, 26, 32), (4, 13, 13, 1024), (1, 52, 52, 64), (3, 7, 5, 8)])
+def test_bn_leaky_forward_backward(ops, shape, mode):
+    B, H, W, C = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rtol = F32_RTOL if mode == 'f32' else BF16_RTOL
+    rng = np.random.RandomState(C)
+    y = (rng.randn(B, H, W, C) * 1.5 + rng.randn(C)).astype(np.float32)
+    da = rng.randn(B, H, W, C).astype(np.float32)
+    gamma = (rng.rand(C) + 0.5).astype(np.float32)
+    beta = (rng.randn(C) * 0.2).astype(np.float32)
+    if mode == 'bf16':
+        y, da = bf16_round(y), bf16_round(da)
+    M = B * H * W
+    mean_r, var_r = R.bn_moments(y)
+    z = R.bn_apply(y, mean_r, var_r, gamma, beta)
+    a_r = R.leaky_relu(z)
+    dy_r, dg_r, db_r = R.bn_train_bwd(y, mean_r, var_r, gamma, R.leaky_relu_grad(z, da))
+
+    yd, dad = dev(y, tdtype), dev(da, tdtype)
+    mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ws = torch.zeros(2 * C, dtype=torch.float64, device='cuda')
+    ops.bn_stats(yd, mean, var, ws, M, C)
+    lda = C + 16
+    A = torch.zeros(M * lda, dtype=tdtype, device='cuda')
+    ops.bn_leaky(yd, mean, var, dev(gamma), dev(beta), A, M, C, lda, 1e-5, 0.1)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_leaky_bwd_reduce(dad, C, yd, mean, var, dev(gamma), dev(beta), dg, db, ws, M, C, 1e-5, 0.1)
+    dY = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky_bwd_apply(dad, C, yd, mean, var, dev(gamma), dev(beta), dg, db, dY, M, C, 1e-5, 0.1)
+    mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    ops.bn_ema(mm, mv, mean, var, C, 0.999)
+    torch.cuda.synchronize()
+    assert_close(host(mean), mean_r, 1e-5, 'mean')
+    assert_close(host(var), var_r, 1e-5, 'var')
+    a = host(A).reshape(M, lda)
+    assert np.all(a[:, C:] == 0)
+    assert_close(a[:, :C].reshape(shape), a_r, rtol, 'bn_leaky')
+    assert_close(host(dg), dg_r, max(rtol, 2e-4), 'dgamma')
+    assert_close(host(db), db_r, max(rtol, 2e-4), 'dbeta')
+    assert_close(host(dY).reshape(shape), dy_r, max(rtol, 2e-4), 'dY')
+    assert_close(host(mm), R.bn_ema(np.zeros(C, np.float32), mean_r), 1e-5, 'ema mean')
+    assert_close(host(mv), R.bn_ema(np.ones(C, np.float32), var_r), 1e-5, 'ema var')
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('stride,shape', [(2, (2, 8, 12, 16)), (2, (1, 26, 26, 512)), (1, (2, 13, 13, 64)), (1, (1, 5, 3, 8))])
+def test_maxpool(ops, stride, shape, mode):
+    B, H, W, C = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(H * W)
+    a = rng.randint(-3, 4, size=shape).astype(np.float32)   # many ties: exercises first-max routing
+    a[0, 0, :, :] = rng.randn(W, C)
+    if mode == 'bf16':
+        a = bf16_round(a)
+    OH, OW = (H // 2, W // 2) if stride == 2 else (H, W)
+    dp = bf16_round(rng.randn(B, OH, OW, C))
+    P = torch.zeros(B * OH * OW * C, dtype=tdtype, device='cuda')
+    dA = torch.full((B * H * W * C,), 9.0, dtype=tdtype, device='cuda')
+    ops.maxpool_fwd(dev(a, tdtype), P, B, H, W, C, stride)
+    ops.maxpool_bwd(dev(a, tdtype), dev(dp, tdtype), dA, B, H, W, C, stride)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(P).reshape(B, OH, OW, C), R.max_pool(a, stride))
+    ref = R.max_pool_grad(a, dp, stride)
+    if mode == 'bf16' and stride == 1:
+        ref = bf16_round(ref)   # overlapping windows sum up to 4 bf16 terms, stored as bf16
+        assert_close(host(dA).reshape(shape), ref, 1e-2, 'pool bwd')
+    else:
+        assert np.array_equal(host(dA).reshape(shape), ref)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_reorg_bit_exact(ops, golden_dir, mode):
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(0)
+    B, H, W, C = 2, 26, 26, 512
+    x = bf16_round(rng.randn(B, H, W, C))
+    ldo = 4 * C + 1024
+    out = torch.zeros(B * (H // 2) * (W // 2) * ldo, dtype=tdtype, device='cuda')
+    ops.reorg(dev(x, tdtype), out, B, H, W, C, ldo)
+    back = torch.zeros(B * H * W * C, dtype=tdtype, device='cuda')
+    ops.reorg_bwd(out, ldo, back, B, H, W, C)
+    torch.cuda.synchronize()
+    o = host(out).reshape(B, H // 2, W // 2, ldo)
+    assert np.array_equal(o[..., :4 * C], R.reorg(x))
+    assert np.all(o[..., 4 * C:] == 0)
+    assert np.array_equal(host(back).reshape(x.shape), x)
+    # the reference's own known-answer test (model/yolo2/function.py:32-47), channels widened to the vector width
+    g = np.load(os.path.join(golden_dir, 'labels.npz'))
+    img = np.repeat(g['reorg/kat_in'].astype(np.float32), 8, axis=3)
+    o2 = torch.zeros(1 * 2 * 2 * 32, dtype=tdtype, device='cuda')
+    ops.reorg(dev(img, tdtype), o2, 1, 4, 4, 8, 32)
+    torch.cuda.synchronize()
+    o2 = host(o2).reshape(2, 2, 4, 8)
+    for i in range(4):
+        assert np.unique(o2[:, :, i, :]).tolist() == [float(g['reorg/kat_channel_values'][i])]
+
+
+def test_copy_add_biasgrad(ops):
+    rng = np.random.RandomState(1)
+    M, C = 338, 125
+    ld = 128
+    dy = np.zeros((M, ld), np.float32)
+    dy[:, :C] = rng.randn(M, C)
+    db = torch.zeros(C, device='cuda')
+    ws = torch.zeros(2 * ld, dtype=torch.float64, device='cuda')
+    ops.bias_grad(dev(dy), ld, db, ws, M, C)
+    dst = torch.zeros(M * 256, device='cuda')
+    ops.copy_channels(dev(dy), ld, dst, 256, M, 64)
+    a, b = rng.randn(4096).astype(np.float32), rng.randn(4096).astype(np.float32)
+    ad = dev(a)
+    ops.add_inplace(ad, dev(b), 4096)
+    torch.cuda.synchronize()
+    assert_close(host(db), dy[:, :C].sum(0), 1e-5, 'bias_grad')
+    d = host(dst).reshape(M, 256)
+    assert np.array_equal(d[:, :64], dy[:, :64]) and np.all(d[:, 64:] == 0)
+    assert np.array_equal(host(ad), a + b)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_image_prep(ops, golden_dir, mode):
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    g = np.load(os.path.join(golden_dir, 'labels.npz'))
+    img = np.stack([g['std/in'], g['std/in'][::-1] * 0.5 + 3])
+    B, H, W, _ = img.shape
+    out = torch.zeros(B * H * W * 8, dtype=tdtype, device='cuda')
+    ws = torch.zeros(2 * B, dtype=torch.float64, device='cuda')
+    ops.image_prep(dev(img), out, ws, B, H * W, 0)
+    torch.cuda.synchronize()
+    o = host(out).reshape(B, H, W, 8)
+    assert np.all(o[..., 3:] == 0)
+    ref = np.stack([R.per_image_standardization(i) for i in img])
+    assert_close(o[..., :3], ref, F32_RTOL if mode == 'f32' else 1e-2, 'standardize')
+    assert_close(o[0, ..., :3], g['std/out'], F32_RTOL if mode == 'f32' else 1e-2, 'standardize vs reference golden')
+    ops.image_prep(dev(img), out, ws, B, H * W, 1)
+    torch.cuda.synchronize()
+    assert_close(host(out).reshape(B, H, W, 8)[..., :3], img / 255., F32_RTOL if mode == 'f32' else 1e-2, 'darknet preprocess')
+
+
+def _labels(rng, B, classes, cw, ch):
+    outs = []
+    for _ in range(B):
+        k = rng.randint(1, 7)
+        cen = rng.uniform(0.05, 0.95, (k, 2))
+        wh = rng.uniform(0.05, 0.6, (k, 2))
+        coord = np.clip(np.concatenate([cen - wh / 2, cen + wh / 2], 1), 0, 1).astype(np.float32)
+        outs.append(R.transform_labels(rng.randint(0, classes, k), coord, classes, cw, ch))
+    return tuple(np.stack([o[i] for o in outs]) for i in range(6))
+
+
+VOC_ANCHORS = np.array([[1.08, 1.19], [3.42, 4.41], [6.63, 11.38], [9.42, 5.11], [16.62, 10.52]], np.float32)
+
+
+@pytest.mark.parametrize('B,classes', [(2, 20), (16, 20), (3, 80)])
+def test_loss_forward_backward_f32(ops, B, classes):
+    rng = np.random.RandomState(B + classes)
+    ch = cw = 13
+    A = 5
+    D = A * (5 + classes)
+    ld = ops.pad8(D)
+    net = (rng.randn(B, ch, cw, D) * 0.7).astype(np.float32)
+    labels = _labels(rng, B, classes, cw, ch)
+    hp = {'iou_best': 5., 'iou_normal': 1., 'coords': 1., 'prob': 1.}
+    m = R.model_decode(net, classes, VOC_ANCHORS, training=True)
+    obj, aux = R.objectives(m, labels)
+    dnet = R.loss_backward(m, labels, aux, hp, classes)
+
+    logits = dev(pad_channels(net, ld))
+    dl = torch.full((B * ch * cw * ld,), 3.0, device='cuda')
+    objs = torch.zeros(4, device='cuda')
+    ws = torch.zeros(ops.loss_ws_floats(B, ch * cw, A), device='cuda')
+    lab = [dev(l.reshape(B, ch * cw, -1)) for l in labels]
+    ops.loss(logits, ld, dev(VOC_ANCHORS), lab, [hp[k] for k in R.OBJECTIVE_KEYS], objs, dl, ws, B, ch, cw, A, classes)
+    torch.cuda.synchronize()
+    got = host(objs)
+    for i, k in enumerate(R.OBJECTIVE_KEYS):
+        assert abs(got[i] - obj[k]) <= F32_RTOL * abs(obj[k]) + 1e-9, (k, got[i], obj[k])
+    d = host(dl).reshape(B, ch, cw, ld)
+    assert np.all(d[..., D:] == 0)
+    assert_close(d[..., :D], dnet, F32_RTOL, 'dlogits')
+
+
+def test_loss_known_answer_zero_logits(ops):
+    """zero logits, no objects -> iou_normal = 0.25, rest 0."""
+    B, ch, cw, A, C = 2, 13, 13, 5, 20
+    ld = 128
+    z = lambda *s: torch.zeros(*s, device='cuda')
+    objs = z(4)
+    ops.loss(z(B * 169 * ld), ld, dev(VOC_ANCHORS), [z(B * 169), z(B * 169 * C), z(B * 169 * 4), z(B * 169 * 2), z(B * 169 * 2), z(B * 169)],
+             [5., 1., 1., 1.], objs, None, z(ops.loss_ws_floats(B, 169, A)), B, ch, cw, A, C)
+    torch.cuda.synchronize()
+    got = host(objs)
+    assert got[0] == 0 and got[2] == 0 and got[3] == 0 and abs(got[1] - 0.25) < 1e-6
+
+
+@pytest.mark.parametrize('classes', [20, 80])
+def test_head_decode_f32(ops, classes):
+    rng = np.random.RandomState(classes)
+    B, ch, cw, A = 3, 13, 13, 5
+    D = A * (5 + classes)
+    ld = ops.pad8(D)
+    net = (rng.randn(B, ch, cw, D)).astype(np.float32)
+    m = R.model_decode(net, classes, VOC_ANCHORS, training=False)
+    conf = torch.zeros(B * 169 * A * classes, device='cuda')
+    mn, mx = torch.zeros(B * 169 * A * 2, device='cuda'), torch.zeros(B * 169 * A * 2, device='cuda')
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.head_decode(dev(pad_channels(net, ld)), ld, dev(VOC_ANCHORS), conf, mn, mx, flag, B, ch, cw, A, classes)
+    torch.cuda.synchronize()
+    assert_close(host(conf).reshape(m['conf'].shape), m['conf'], F32_RTOL, 'conf')
+    assert_close(host(mn).reshape(m['xy_min'].shape), m['xy_min'], F32_RTOL, 'xy_min')
+    assert_close(host(mx).reshape(m['xy_max'].shape), m['xy_max'], F32_RTOL, 'xy_max')
+    assert int(flag.item()) == 0
+    bad = net.copy()
+    bad[0, 0, 0, 3] = np.inf
+    ops.head_decode(dev(pad_channels(bad, ld)), ld, dev(VOC_ANCHORS), conf, mn, mx, flag, B, ch, cw, A, classes)
+    torch.cuda.synchronize()
+    assert int(flag.item()) != 0       # tf.check_numerics counterpart (detect.py:70)
+
+
+NMS_CASES = ['sparse20', 'sparse80', 'dense', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
+
+
+def _gpu_nms(ops, conf, mn, mx, thr, thr_iou):
+    B, N, C = conf.shape
+    cd = dev(conf)
+    order = torch.zeros(B * N, dtype=torch.int32, device='cuda')
+    ws = torch.zeros(B * N * C, dtype=torch.int32, device='cuda')
+    ops.nms(cd, dev(mn), dev(mx), order, ws, B, N, C, thr, thr_iou)
+    torch.cuda.synchronize()
+    return host(cd).reshape(B, N, C), order.cpu().numpy().reshape(B, N)
+
+
+def test_nms_reference_goldens_bit_exact(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'nms.npz'))
+    for case in NMS_CASES:
+        conf = g[case + '/conf_in']
+        cells, A, C = conf.shape
+        got, order = _gpu_nms(ops, conf.reshape(1, cells * A, C), g[case + '/xy_min'].reshape(1, -1, 2), g[case + '/xy_max'].reshape(1, -1, 2),
+                              float(g[case + '/thr']), float(g[case + '/thr_iou']))
+        assert np.array_equal(got[0], g[case + '/conf_out'].reshape(cells * A, C)), case
+        assert np.array_equal(order[0], g[case + '/order']), case
+
+
+def _c_nms(conf, mn, mx, thr, thr_iou):
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libnms_ref.so'))
+    n, c = conf.shape
+    conf = np.ascontiguousarray(conf, np.float32).copy()
+    order = np.zeros(n, np.int64)
+    P = ctypes.POINTER(ctypes.c_float)
+    lib.nms_ref(conf.ctypes.data_as(P), np.ascontiguousarray(mn, np.float32).ctypes.data_as(P), np.ascontiguousarray(mx, np.float32).ctypes.data_as(P),
+                ctypes.c_long(n), ctypes.c_long(c), ctypes.c_float(thr), ctypes.c_float(thr_iou), order.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
+    return conf, order
+
+
+@pytest.mark.parametrize('B,N,C,dense', [(8, 845, 20, False), (4, 845, 80, False), (2, 845, 20, True), (2, 1805, 20, False), (3, 100, 3, True)])
+def test_nms_batched_vs_c_oracle(ops, B, N, C, dense):
+    rng = np.random.RandomState(N + C)
+    if dense:
+        conf = rng.uniform(0, 0.5, (B, N, C)).astype(np.float32)
+        conf[rng.rand(B, N, C) < 0.1] = 0.4          # ties
+    else:
+        conf = rng.uniform(0, 0.05, (B, N, C)).astype(np.float32)
+        for b in range(B):
+            hot = rng.choice(N, 40, replace=False)
+            conf[b, hot, rng.randint(0, C, 40)] = rng.uniform(0.3, 0.95, 40).astype(np.float32)
+    cen = rng.uniform(0, 13, (B, N, 2)).astype(np.float32)
+    wh = rng.uniform(0.5, 5.5, (B, N, 2)).astype(np.float32)
+    mn, mx = (cen - wh / 2).astype(np.float32), (cen + wh / 2).astype(np.float32)
+    got, order = _gpu_nms(ops, conf, mn, mx, 0.3, 0.4)
+    for b in range(B):
+        rc, ro = _c_nms(conf[b], mn[b], mx[b], 0.3, 0.4)
+        assert np.array_equal(got[b], rc), 'image %d: %d scores differ' % (b, (got[b] != rc).sum())
+        assert np.array_equal(order[b], ro)
+        # keep-set as the consumer sees it (detect.py:78-80)
+        keep_g = {(i, int(np.argmax(got[b, i]))) for i in range(N) if got[b, i].max() > 0.3}
+        keep_r = {(i, int(np.argmax(rc[i]))) for i in range(N) if rc[i].max() > 0.3}
+        assert keep_g == keep_r
+
+
+def test_optimizers_vs_oracle(ops):
+    rng = np.random.RandomState(5)
+    n = 10007
+    w0, g = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    s1, s2 = (rng.rand(n) * 0.1).astype(np.float32), (rng.rand(n) * 0.1).astype(np.float32)
+    # adam, two steps
+    w, m, v = dev(w0), dev(np.zeros(n, np.float32)), dev(np.zeros(n, np.float32))
+    rw, rm, rv = w0, np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t in (1, 2):
+        alpha = 1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam(w, dev(g), m, v, n, float(alpha), 0.9, 0.999, 1e-8)
+        rw, rm, rv = R.adam_step(rw, g, rm, rv, 1e-3, t)
+    torch.cuda.synchronize()
+    assert_close(host(w), rw, 1e-6, 'adam w')
+    assert_close(host(m), rm, 1e-6, 'adam m')
+    assert_close(host(v), rv, 1e-6, 'adam v')
+    w, a = dev(w0), dev(s1)
+    ops.momentum(w, dev(g), a, n, 0.01, 0.9)
+    rw, ra = R.momentum_step(w0, g, s1, 0.01, 0.9)
+    assert_close(host(w), rw, 1e-6, 'momentum')
+    w = dev(w0)
+    ops.sgd(w, dev(g), n, 0.01)
+    assert_close(host(w), R.gd_step(w0, g, 0.01), 1e-6, 'sgd')
+    w, a, b = dev(w0), dev(s1), dev(s2)
+    ops.rmsprop(w, dev(g), a, b, n, 0.01, 0.9, 0.5, 1e-10)
+    rw, _, _ = R.rmsprop_step(w0, g, s1, s2, 0.01, 0.9, 0.5, 1e-10)
+    assert_close(host(w), rw, 1e-5, 'rmsprop')
+    w, a = dev(w0), dev(s1 + 0.1)
+    ops.adagrad(w, dev(g), a, n, 0.01)
+    rw, _ = R.adagrad_step(w0, g, s1 + 0.1, 0.01)
+    assert_close(host(w), rw, 1e-6, 'adagrad')
+    w, a, b = dev(w0), dev(s1), dev(s2)
+    ops.adadelta(w, dev(g), a, b, n, 1.0, 0.95, 1e-8)
+    rw, _, _ = R.adadelta_step(w0, g, s1, s2, 1.0, 0.95, 1e-8)
+    assert_close(host(w), rw, 1e-5, 'adadelta')
+    # per-tensor clip_by_norm
+    seg = np.array([0, 100, 5000, n], np.int64)
+    gd = dev(g)
+    ops.clip_by_norm(gd, torch.from_numpy(seg).cuda(), 3, 5.0, torch.zeros(3, dtype=torch.float64, device='cuda'))
+    torch.cuda.synchronize()
+    ref = np.concatenate([R.clip_by_norm(g[seg[i]:seg[i + 1]], 5.0) for i in range(3)])
+    assert_close(host(gd), ref, 1e-6, 'clip_by_norm')

@@ -1,0 +1,102 @@
+"""ctypes binding of include/yolo2_hip.h (libyolo2hip.so, hand-written HIP for gfx950).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved, importing
+the compute path raises.  Every wrapper converts a non-zero status into ``HipKernelError`` carrying
+``yolo2_last_error()``, mirroring the reference's behaviour of raising Python exceptions
+(assert / tf.check_numerics) instead of returning codes.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libyolo2hip.so')
+
+F32, BF16 = 0, 1
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+
+# name -> argument ctypes (return type is always int unless noted)
+SIGNATURES = {
+    'yolo2_conv2d': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_conv2d_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],
+    'yolo2_bn_ema': [_p, _p, _p, _p, _i, _f, _p],
+    'yolo2_bn_leaky': [_p, _p, _p, _p, _p, _p, _l, _i, _i, _f, _f, _i, _p],
+    'yolo2_bn_leaky_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _f, _i, _p],
+    'yolo2_bn_leaky_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _f, _i, _p],
+    'yolo2_maxpool_fwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_maxpool_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_reorg': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_reorg_bwd': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'yolo2_copy_channels': [_p, _i, _p, _i, _l, _i, _i, _p],
+    'yolo2_add_inplace': [_p, _p, _l, _i, _p],
+    'yolo2_bias_grad': [_p, _i, _p, _p, _l, _i, _i, _p],
+    'yolo2_image_prep': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'yolo2_head_decode': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_nms': [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
+    'yolo2_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
+    'yolo2_momentum': [_p, _p, _p, _l, _f, _f, _f, _p],
+    'yolo2_sgd': [_p, _p, _l, _f, _f, _p],
+    'yolo2_rmsprop': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
+    'yolo2_adagrad': [_p, _p, _p, _l, _f, _f, _p],
+    'yolo2_adadelta': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _p],
+    'yolo2_clip_by_norm': [_p, _p, _i, _f, _p, _p],
+    'yolo2_selftest_tr16': [_p, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Loads libyolo2hip.so and resolves every symbol of the header; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipKernelError(
+            'HIP extension %s is missing: run `python yolo_tf_amd/csrc/build.py` (or __graft_entry__.build()). '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.yolo2_last_error.restype = ctypes.c_char_p
+    lib.yolo2_last_error.argtypes = []
+    lib.yolo2_abi_version.restype = _i
+    lib.yolo2_abi_version.argtypes = []
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = _i
+        fn.argtypes = args
+    lib.yolo2_debug_set_wgrad_variant.restype = None
+    lib.yolo2_debug_set_wgrad_variant.argtypes = [_i]
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise HipKernelError('%s failed (code %d): %s' % (name, rc, lib.yolo2_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(torch_dtype):
+    import torch
+    if torch_dtype == torch.float32:
+        return F32
+    if torch_dtype == torch.bfloat16:
+        return BF16
+    raise ValueError('unsupported dtype %r' % (torch_dtype,))

@@ -1,0 +1,51 @@
+"""Builds libyolo2hip.so (the C-ABI library of include/yolo2_hip.h) for gfx950 with hipcc.
+
+In-tree, explicit: `python yolo_tf_amd/csrc/build.py` (also called by __graft_entry__.build()).
+hipcc cross-compiles without a GPU.  The exact-compare kernels (loss IoU equality, NMS) are built
+with FP contraction off."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = {
+    'conv_igemm.hip': [],
+    'conv_wgrad.hip': [],
+    'elementwise.hip': [],
+    'head.hip': ['-ffp-contract=off'],
+    'nms.hip': ['-ffp-contract=off'],
+}
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
+LIB = os.path.join(HERE, 'libyolo2hip.so')
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    headers = [os.path.join(HERE, 'common.h'), os.path.join(HERE, '..', '..', 'include', 'yolo2_hip.h'), os.path.abspath(__file__)]
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + headers):
+            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 YOLOv2 kernels (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/yolo2_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void yolo2_set_error(const char *fmt, ...);
+
+#define Y2_CHECK_ARG(cond)                                                          \
+    do {                                                                            \
+        if (!(cond)) {                                                              \
+            yolo2_set_error("%s: argument check failed: %s", __func__, #cond);      \
+            return YOLO2_E_ARG;                                                     \
+        }                                                                           \
+    } while (0)
+
+#define Y2_CHECK_LAUNCH()                                                           \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            yolo2_set_error("%s: HIP error: %s", __func__, hipGetErrorString(e_));  \
+            return YOLO2_E_LAUNCH;                                                  \
+        }                                                                           \
+    } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// 16-byte vector of T: 4 floats or 8 bf16
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4 v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    bf16x8 v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16)x; }
+};
+
+template <typename T> __device__ __forceinline__ Vec16<T> ld16(const T *p) {
+    Vec16<T> r;
+    r.v = *reinterpret_cast<const decltype(r.v) *>(p);
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T *p, const Vec16<T> &x) {
+    *reinterpret_cast<decltype(x.v) *>(p) = x.v;
+}
+template <typename T> __device__ __forceinline__ Vec16<T> zero16() {
+    Vec16<T> r;
+#pragma unroll
+    for (int i = 0; i < Vec16<T>::N; ++i) r.set(i, 0.f);
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define Y2_DISPATCH_DTYPE(dtype, ...)                                   \
+    do {                                                                \
+        if ((dtype) == YOLO2_F32) { typedef float T; __VA_ARGS__; }     \
+        else if ((dtype) == YOLO2_BF16) { typedef bf16 T; __VA_ARGS__; } \
+        else { yolo2_set_error("%s: bad dtype %d", __func__, (int)(dtype)); return YOLO2_E_ARG; } \
+    } while (0)

@@ -1,0 +1,781 @@
+// HBM-bound kernels of the YOLOv2 path (gfx950): filter layout prep, batch-norm statistics /
+// apply / backward fused with leaky ReLU, 2x2 max pool, reorg (space-to-depth) and channel
+// concat moves, image standardisation, bias gradient, optimizers.
+// All activation traffic is 16-byte vectors (8 bf16 / 4 f32) with lanes running along the
+// contiguous NHWC channel axis; per-channel parameters stay in registers because every thread
+// keeps a fixed channel group while it strides over pixels.
+#include "common.h"
+#include <stdarg.h>
+
+// ------------------------------------------------------------------------------------------
+// error string (thread local) + misc ABI
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void yolo2_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char *yolo2_last_error(void) { return g_err; }
+extern "C" int yolo2_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------
+// filter prep: HWIO f32 -> K-contiguous operand layouts (reference stores conv weights HWIO,
+// parse_darknet_yolo2.py:95-97)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void filter_fwd_kernel(const float *__restrict__ Wt, T *__restrict__ F, int Cin, int ldcin, int Cout, int taps) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, n = n0 + tx;
+        tile[i][tx] = (c < Cin && n < Cout) ? Wt[((long)tap * Cin + c) * Cout + n] : 0.f;
+    }
+    __syncthreads();
+    const long Kf = (long)taps * ldcin;
+    for (int i = ty; i < 32; i += 8) {
+        int n = n0 + i, c = c0 + tx;
+        if (n < Cout && c < ldcin) F[n * Kf + (long)tap * ldcin + c] = (T)tile[tx][i];
+    }
+}
+template <typename T>
+__global__ void filter_dgrad_kernel(const float *__restrict__ Wt, T *__restrict__ F, int Cin, int Cout, int ldcout, int taps) {
+    const long total = (long)Cin * taps * ldcout;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i % ldcout);
+        long r = i / ldcout;
+        int tp = (int)(r % taps);
+        int c = (int)(r / taps);
+        float v = n < Cout ? Wt[((long)(taps - 1 - tp) * Cin + c) * Cout + n] : 0.f;
+        F[i] = (T)v;
+    }
+}
+
+extern "C" int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin, int ldcin,
+                                 int Cout, int ldcout, int dtype, void *stream) {
+    Y2_CHECK_ARG(W && (Ffwd || Fdgr));
+    Y2_CHECK_ARG(ksize == 1 || ksize == 3);
+    Y2_CHECK_ARG(ldcin >= Cin && ldcout >= Cout);
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = ksize * ksize;
+    if (Ffwd) {
+        dim3 grid(cdiv(Cout, 32), cdiv(ldcin, 32), taps), block(32, 8);
+        Y2_DISPATCH_DTYPE(dtype, filter_fwd_kernel<T><<<grid, block, 0, st>>>(W, (T *)Ffwd, Cin, ldcin, Cout, taps));
+    }
+    if (Fdgr) {
+        long total = (long)Cin * taps * ldcout;
+        int grid = (int)(total / 256 + 1 < 4096 ? total / 256 + 1 : 4096);
+        Y2_DISPATCH_DTYPE(dtype, filter_dgrad_kernel<T><<<grid, 256, 0, st>>>(W, (T *)Fdgr, Cin, Cout, ldcout, taps));
+    }
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// column reductions over [M][C] (pixel stride ld): sum, centred sum of squares, BN backward sums
+// ------------------------------------------------------------------------------------------
+struct RowMap {  // fixed channel group per thread, rows strided
+    int tpr, rpp, cg, rs;
+    bool active;
+    __device__ RowMap(int C, int vec) {
+        tpr = C / vec;
+        rpp = 256 / tpr;
+        if (rpp < 1) rpp = 1;
+        cg = threadIdx.x % tpr;
+        rs = threadIdx.x / tpr;
+        active = rs < rpp && threadIdx.x < tpr * rpp;
+    }
+};
+
+// reduce V per-thread partial vectors (N values each) across the row slots of a block and add
+// the per-channel totals to double accumulators out[k*C + c]
+template <int N, int K>
+__device__ __forceinline__ void block_colsum_commit(const float (&part)[K][N], const RowMap &rm, int C, double *out) {
+    __shared__ float red[K][256 * 8 / 8][N];  // [K][256][N] floats: N<=8, K<=2 -> 16 KB
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < N; ++j) red[k][threadIdx.x][j] = rm.active ? part[k][j] : 0.f;
+    }
+    __syncthreads();
+    if (threadIdx.x < rm.tpr) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double s = 0.0;
+                for (int r = 0; r < rm.rpp; ++r) s += (double)red[k][r * rm.tpr + threadIdx.x][j];
+                atomicAdd(out + (long)k * C + threadIdx.x * N + j, s);
+            }
+    }
+}
+
+// MODE 0: sum x ; MODE 1: sum (x - mean)^2 with mean = ws_sum/M
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, const double *__restrict__ sum_in, double *__restrict__ out) {
+    constexpr int N = Vec16<T>::N;
+    RowMap rm(C, N);
+    float part[1][N];
+    float mean[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        part[0][j] = 0.f;
+        mean[j] = (MODE == 1 && rm.active) ? (float)(sum_in[rm.cg * N + j] / (double)M) : 0.f;
+    }
+    if (rm.active) {
+        for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
+            Vec16<T> v = ld16(X + r * ld + rm.cg * N);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float x = v.get(j);
+                if (MODE == 0) part[0][j] += x;
+                else { float d = x - mean[j]; part[0][j] += d * d; }
+            }
+        }
+    }
+    block_colsum_commit<N, 1>(part, rm, C, out);
+}
+
+__global__ void bn_finalize_kernel(const double *__restrict__ ws, float *__restrict__ mean, float *__restrict__ var, long M, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mean[c] = (float)(ws[c] / (double)M);
+        var[c] = (float)(ws[C + c] / (double)M);
+    }
+}
+__global__ void colsum_finalize_kernel(const double *__restrict__ ws, float *__restrict__ out, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (float)ws[c];
+}
+
+static int colsum_grid(long M, int C, int vec) {
+    int tpr = C / vec, rpp = 256 / tpr;
+    if (rpp < 1) rpp = 1;
+    long g = (M + (long)rpp * 8 - 1) / ((long)rpp * 8);
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(Y && mean && var && ws && M > 0 && C > 0);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { yolo2_set_error("bn_stats: memset failed"); return YOLO2_E_LAUNCH; }
+    int grid = colsum_grid(M, C, vec);
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 0><<<grid, 256, 0, st>>>((const T *)Y, C, M, C, nullptr, ws));
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 1><<<grid, 256, 0, st>>>((const T *)Y, C, M, C, ws, ws + C));
+    bn_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, mean, var, M, C);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(dY && dbias && ws && M > 0 && C > 0 && ld >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(ld % vec == 0 && ld / vec <= 256);
+    hipStream_t st = (hipStream_t)stream;
+    // reduce over the padded width ld (padding lanes are zero by contract), report the first C
+    if (hipMemsetAsync(ws, 0, sizeof(double) * ld, st) != hipSuccess) { yolo2_set_error("bias_grad: memset failed"); return YOLO2_E_LAUNCH; }
+    int grid = colsum_grid(M, ld, vec);
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 0><<<grid, 256, 0, st>>>((const T *)dY, ld, M, ld, nullptr, ws));
+    colsum_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, dbias, C);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+__global__ void bn_ema_kernel(float *mm, float *mv, const float *mean, const float *var, int C, float one_minus_decay) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mm[c] = mm[c] - (mm[c] - mean[c]) * one_minus_decay;
+        mv[c] = mv[c] - (mv[c] - var[c]) * one_minus_decay;
+    }
+}
+extern "C" int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var, int C, float decay, void *stream) {
+    Y2_CHECK_ARG(moving_mean && moving_var && mean && var && C > 0);
+    bn_ema_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(moving_mean, moving_var, mean, var, C, 1.0f - decay);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// BN apply + leaky (forward), BN+leaky backward
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_leaky_kernel(const T *__restrict__ Y, const float *__restrict__ mean, const float *__restrict__ var,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta, T *__restrict__ A,
+                                                       long M, int C, int lda, float eps, float alpha) {
+    constexpr int N = Vec16<T>::N;
+    RowMap rm(C, N);
+    if (!rm.active) return;
+    float mu[N], sc[N], bt[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        int c = rm.cg * N + j;
+        mu[j] = mean[c];
+        sc[j] = (1.0f / sqrtf(var[c] + eps)) * gamma[c];
+        bt[j] = beta[c];
+    }
+    for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
+        Vec16<T> v = ld16(Y + r * C + rm.cg * N), o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float z = (v.get(j) - mu[j]) * sc[j] + bt[j];
+            o.set(j, fmaxf(z, alpha * z));
+        }
+        st16(A + r * lda + rm.cg * N, o);
+    }
+}
+
+static int rowmap_grid(long M, int C, int vec, int rows_per_thread) {
+    int tpr = C / vec, rpp = 256 / tpr;
+    if (rpp < 1) rpp = 1;
+    long g = (M + (long)rpp * rows_per_thread - 1) / ((long)rpp * rows_per_thread);
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int yolo2_bn_leaky(const void *Y, const float *mean, const float *var, const float *gamma, const float *beta,
+                              void *A, long M, int C, int lda, float eps, float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(Y && mean && var && gamma && beta && A && M > 0 && C > 0 && lda >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && lda % vec == 0);
+    int grid = rowmap_grid(M, C, vec, 4);
+    Y2_DISPATCH_DTYPE(dtype, bn_leaky_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, mean, var, gamma, beta, (T *)A, M, C, lda, eps, alpha));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ dA, int ldda, const T *__restrict__ Y, const float *__restrict__ mean,
+                                                            const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            double *__restrict__ ws, long M, int C, float eps, float alpha) {
+    constexpr int N = Vec16<T>::N;
+    RowMap rm(C, N);
+    float part[2][N];
+    float mu[N], inv[N], ga[N], bt[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        part[0][j] = part[1][j] = 0.f;
+        int c = rm.cg * N + j;
+        bool ok = rm.active;
+        mu[j] = ok ? mean[c] : 0.f;
+        inv[j] = ok ? 1.0f / sqrtf(var[c] + eps) : 0.f;
+        ga[j] = ok ? gamma[c] : 0.f;
+        bt[j] = ok ? beta[c] : 0.f;
+    }
+    if (rm.active) {
+        for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
+            Vec16<T> y = ld16(Y + r * C + rm.cg * N), d = ld16(dA + r * ldda + rm.cg * N);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float xh = (y.get(j) - mu[j]) * inv[j];
+                float z = (y.get(j) - mu[j]) * (inv[j] * ga[j]) + bt[j];
+                float g = z >= 0.f ? d.get(j) : alpha * d.get(j);
+                part[0][j] += g * xh;  // dgamma
+                part[1][j] += g;       // dbeta
+            }
+        }
+    }
+    block_colsum_commit<N, 2>(part, rm, C, ws);
+}
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ ws, float *dgamma, float *dbeta, int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { dgamma[c] = (float)ws[c]; dbeta[c] = (float)ws[C + c]; }
+}
+
+extern "C" int yolo2_bn_leaky_bwd_reduce(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
+                                         const float *beta, float *dgamma, float *dbeta, double *ws, long M, int C, float eps, float alpha,
+                                         int dtype, void *stream) {
+    Y2_CHECK_ARG(dA && Y && mean && var && gamma && beta && dgamma && dbeta && ws && M > 0 && C > 0 && ldda >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { yolo2_set_error("bn_bwd_reduce: memset failed"); return YOLO2_E_LAUNCH; }
+    int grid = colsum_grid(M, C, vec);
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_reduce_kernel<T><<<grid, 256, 0, st>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, ws, M, C, eps, alpha));
+    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, dgamma, dbeta, C);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T *__restrict__ dA, int ldda, const T *__restrict__ Y, const float *__restrict__ mean,
+                                                           const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ dgamma, const float *__restrict__ dbeta, T *__restrict__ dY,
+                                                           long M, int C, float eps, float alpha) {
+    constexpr int N = Vec16<T>::N;
+    RowMap rm(C, N);
+    if (!rm.active) return;
+    const float invM = 1.0f / (float)M;
+    float mu[N], inv[N], ga[N], bt[N], dgm[N], dbm[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        int c = rm.cg * N + j;
+        mu[j] = mean[c];
+        inv[j] = 1.0f / sqrtf(var[c] + eps);
+        ga[j] = gamma[c];
+        bt[j] = beta[c];
+        dgm[j] = dgamma[c] * invM;
+        dbm[j] = dbeta[c] * invM;
+    }
+    for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
+        Vec16<T> y = ld16(Y + r * C + rm.cg * N), d = ld16(dA + r * ldda + rm.cg * N), o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float xh = (y.get(j) - mu[j]) * inv[j];
+            float z = (y.get(j) - mu[j]) * (inv[j] * ga[j]) + bt[j];
+            float g = z >= 0.f ? d.get(j) : alpha * d.get(j);
+            o.set(j, (ga[j] * inv[j]) * (g - dbm[j] - xh * dgm[j]));
+        }
+        st16(dY + r * C + rm.cg * N, o);
+    }
+}
+
+extern "C" int yolo2_bn_leaky_bwd_apply(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
+                                        const float *beta, const float *dgamma, const float *dbeta, void *dY, long M, int C, float eps,
+                                        float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(dA && Y && mean && var && gamma && beta && dgamma && dbeta && dY && M > 0 && C > 0 && ldda >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
+    int grid = rowmap_grid(M, C, vec, 4);
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_apply_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, dgamma, dbeta, (T *)dY, M, C, eps, alpha));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// max pool 2x2 SAME
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T *__restrict__ A, T *__restrict__ P, int B, int H, int W, int C, int stride) {
+    constexpr int N = Vec16<T>::N;
+    const int OH = stride == 2 ? H / 2 : H, OW = stride == 2 ? W / 2 : W;
+    const int cgs = C / N;
+    const long total = (long)B * OH * OW * cgs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        long p = i / cgs;
+        int ow = (int)(p % OW);
+        long q = p / OW;
+        int oh = (int)(q % OH);
+        int b = (int)(q / OH);
+        const int h0 = oh * stride, w0 = ow * stride;
+        Vec16<T> m = ld16(A + (((long)b * H + h0) * W + w0) * C + cg * N);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            int hh = h0 + (k >> 1), ww = w0 + (k & 1);
+            if (hh < H && ww < W) {
+                Vec16<T> v = ld16(A + (((long)b * H + hh) * W + ww) * C + cg * N);
+#pragma unroll
+                for (int j = 0; j < N; ++j) m.set(j, fmaxf(m.get(j), v.get(j)));
+            }
+        }
+        st16(P + p * C + cg * N, m);
+    }
+}
+
+// stride 2: one thread per pooled chunk writes all four input positions (full overwrite of dA)
+template <typename T>
+__global__ void maxpool_bwd_s2_kernel(const T *__restrict__ A, const T *__restrict__ dP, T *__restrict__ dA, int B, int H, int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int OH = H / 2, OW = W / 2, cgs = C / N;
+    const long total = (long)B * OH * OW * cgs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        long p = i / cgs;
+        int ow = (int)(p % OW);
+        long q = p / OW;
+        int oh = (int)(q % OH);
+        int b = (int)(q / OH);
+        Vec16<T> v[4], o[4];
+        const long base = (((long)b * H + oh * 2) * W + ow * 2) * C + cg * N;
+        v[0] = ld16(A + base);
+        v[1] = ld16(A + base + C);
+        v[2] = ld16(A + base + (long)W * C);
+        v[3] = ld16(A + base + (long)W * C + C);
+        Vec16<T> g = ld16(dP + p * C + cg * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float m = fmaxf(fmaxf(v[0].get(j), v[1].get(j)), fmaxf(v[2].get(j), v[3].get(j)));
+            int arg = v[0].get(j) == m ? 0 : v[1].get(j) == m ? 1 : v[2].get(j) == m ? 2 : 3;  // first max in scan order
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k].set(j, k == arg ? g.get(j) : 0.f);
+        }
+        st16(dA + base, o[0]);
+        st16(dA + base + C, o[1]);
+        st16(dA + base + (long)W * C, o[2]);
+        st16(dA + base + (long)W * C + C, o[3]);
+    }
+}
+
+// stride 1 (tiny model): one thread per INPUT chunk gathers from the <=4 windows containing it
+template <typename T>
+__global__ void maxpool_bwd_s1_kernel(const T *__restrict__ A, const T *__restrict__ dP, T *__restrict__ dA, int B, int H, int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cgs = C / N;
+    const long total = (long)B * H * W * cgs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        long p = i / cgs;
+        int w = (int)(p % W);
+        long q = p / W;
+        int h = (int)(q % H);
+        int b = (int)(q / H);
+        float acc[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] = 0.f;
+        for (int oh = h - 1; oh <= h; ++oh) {
+            if (oh < 0) continue;
+            for (int ow = w - 1; ow <= w; ++ow) {
+                if (ow < 0) continue;
+                // window (oh, ow) covers (oh..oh+1, ow..ow+1); position of (h, w) inside it:
+                const int mypos = (h - oh) * 2 + (w - ow);
+                Vec16<T> v[4];
+                bool ok[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int hh = oh + (k >> 1), ww = ow + (k & 1);
+                    ok[k] = hh < H && ww < W;
+                    v[k] = ok[k] ? ld16(A + (((long)b * H + hh) * W + ww) * C + cg * N) : zero16<T>();
+                }
+                Vec16<T> g = ld16(dP + (((long)b * H + oh) * W + ow) * C + cg * N);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (ok[k]) m = fmaxf(m, v[k].get(j));
+                    int arg = 3;
+#pragma unroll
+                    for (int k = 3; k >= 0; --k) if (ok[k] && v[k].get(j) == m) arg = k;
+                    if (arg == mypos) acc[j] += g.get(j);
+                }
+            }
+        }
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) o.set(j, acc[j]);
+        st16(dA + p * C + cg * N, o);
+    }
+}
+
+static int ew_grid(long total) {
+    long g = (total + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int yolo2_maxpool_fwd(const void *A, void *P, int B, int H, int W, int C, int stride, int dtype, void *stream) {
+    Y2_CHECK_ARG(A && P && B > 0 && H > 0 && W > 0 && C > 0);
+    Y2_CHECK_ARG(stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0));
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0);
+    long total = (long)B * (stride == 2 ? H / 2 : H) * (stride == 2 ? W / 2 : W) * (C / vec);
+    Y2_DISPATCH_DTYPE(dtype, maxpool_fwd_kernel<T><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T *)A, (T *)P, B, H, W, C, stride));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_maxpool_bwd(const void *A, const void *dP, void *dA, int B, int H, int W, int C, int stride, int dtype, void *stream) {
+    Y2_CHECK_ARG(A && dP && dA && B > 0 && H > 0 && W > 0 && C > 0);
+    Y2_CHECK_ARG(stride == 1 || (stride == 2 && H % 2 == 0 && W % 2 == 0));
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 2) {
+        long total = (long)B * (H / 2) * (W / 2) * (C / vec);
+        Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s2_kernel<T><<<ew_grid(total), 256, 0, st>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
+    } else {
+        long total = (long)B * H * W * (C / vec);
+        Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s1_kernel<T><<<ew_grid(total), 256, 0, st>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
+    }
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// reorg (space-to-depth, model/yolo2/function.py:22-29) and channel-slice moves
+// ------------------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ void reorg_kernel(const T *__restrict__ src, T *__restrict__ dst, int B, int H, int W, int C, int ld) {
+    // forward: src = in [B,H,W,C], dst = out [B,H/2,W/2,ld];  backward: src = dout (stride ld), dst = din
+    constexpr int N = Vec16<T>::N;
+    const int OH = H / 2, OW = W / 2, cgs = C / N;
+    const long total = (long)B * H * W * cgs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        long p = i / cgs;  // input pixel index (b, h, w)
+        int w = (int)(p % W);
+        long q = p / W;
+        int h = (int)(q % H);
+        int b = (int)(q / H);
+        const long in_off = p * C + cg * N;
+        const long out_off = (((long)b * OH + (h >> 1)) * OW + (w >> 1)) * ld + ((h & 1) * 2 + (w & 1)) * C + cg * N;
+        if (!BWD) st16(dst + out_off, ld16(src + in_off));
+        else st16(dst + in_off, ld16(src + out_off));
+    }
+}
+extern "C" int yolo2_reorg(const void *in, void *out, int B, int H, int W, int C, int ldo, int dtype, void *stream) {
+    Y2_CHECK_ARG(in && out && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && ldo >= 4 * C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && ldo % vec == 0);
+    long total = (long)B * H * W * (C / vec);
+    Y2_DISPATCH_DTYPE(dtype, reorg_kernel<T, false><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T *)in, (T *)out, B, H, W, C, ldo));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_reorg_bwd(const void *dout, int ldd, void *din, int B, int H, int W, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(dout && din && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && ldd >= 4 * C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && ldd % vec == 0);
+    long total = (long)B * H * W * (C / vec);
+    Y2_DISPATCH_DTYPE(dtype, reorg_kernel<T, true><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T *)dout, (T *)din, B, H, W, C, ldd));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T *__restrict__ src, int lds, T *__restrict__ dst, int ldd, long M, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cgs = C / N;
+    const long total = M * cgs;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int cg = (int)(i % cgs);
+        long r = i / cgs;
+        st16(dst + r * ldd + cg * N, ld16(src + r * lds + cg * N));
+    }
+}
+extern "C" int yolo2_copy_channels(const void *src, int lds, void *dst, int ldd, long M, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(src && dst && M > 0 && C > 0 && lds >= C && ldd >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && lds % vec == 0 && ldd % vec == 0);
+    Y2_DISPATCH_DTYPE(dtype, copy_channels_kernel<T><<<ew_grid(M * (C / vec)), 256, 0, (hipStream_t)stream>>>((const T *)src, lds, (T *)dst, ldd, M, C));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+template <typename T>
+__global__ void add_inplace_kernel(T *__restrict__ dst, const T *__restrict__ src, long nvec) {
+    constexpr int N = Vec16<T>::N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        Vec16<T> a = ld16(dst + i * N), b = ld16(src + i * N), o;
+#pragma unroll
+        for (int j = 0; j < N; ++j) o.set(j, a.get(j) + b.get(j));
+        st16(dst + i * N, o);
+    }
+}
+extern "C" int yolo2_add_inplace(void *dst, const void *src, long n, int dtype, void *stream) {
+    Y2_CHECK_ARG(dst && src && n > 0);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(n % vec == 0);
+    Y2_DISPATCH_DTYPE(dtype, add_inplace_kernel<T><<<ew_grid(n / vec), 256, 0, (hipStream_t)stream>>>((T *)dst, (const T *)src, n / vec));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// image prep (tf.image.per_image_standardization, train.py:103; utils/preprocess.py:23-25)
+// ------------------------------------------------------------------------------------------
+__global__ void image_sums_kernel(const float *__restrict__ img, double *__restrict__ ws, long n_per_image) {
+    const int b = blockIdx.y;
+    const float *p = img + (long)b * n_per_image;
+    double s = 0.0, q = 0.0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_per_image; i += (long)gridDim.x * blockDim.x) {
+        double v = (double)p[i];
+        s += v;
+        q += v * v;
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(ws + 2 * b, s);
+        atomicAdd(ws + 2 * b + 1, q);
+    }
+}
+template <typename T>
+__global__ void image_apply_kernel(const float *__restrict__ img, T *__restrict__ out, const double *__restrict__ ws, int B, long HW, int mode) {
+    const long total = (long)B * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int b = (int)(i / HW);
+        float sub = 0.f, den = 1.f;
+        if (mode == 0) {
+            const double n = (double)HW * 3.0;
+            double mean = ws[2 * b] / n;
+            double var = ws[2 * b + 1] / n - mean * mean;
+            if (var < 0) var = 0;
+            sub = (float)mean;
+            den = fmaxf((float)sqrt(var), (float)(1.0 / sqrt(n)));
+        } else if (mode == 1) {
+            den = 255.0f;
+        }
+        const float *p = img + i * 3;
+        T *o = out + i * 8;
+        float v0 = p[0], v1 = p[1], v2 = p[2];
+        if (mode != 2) { v0 = (v0 - sub) / den; v1 = (v1 - sub) / den; v2 = (v2 - sub) / den; }
+        o[0] = (T)v0; o[1] = (T)v1; o[2] = (T)v2;
+        o[3] = (T)0.f; o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; o[7] = (T)0.f;
+    }
+}
+extern "C" int yolo2_image_prep(const float *img, void *out, double *ws, int B, int HW, int mode, int dtype, void *stream) {
+    Y2_CHECK_ARG(img && out && B > 0 && HW > 0 && mode >= 0 && mode <= 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {
+        Y2_CHECK_ARG(ws);
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, st) != hipSuccess) { yolo2_set_error("image_prep: memset failed"); return YOLO2_E_LAUNCH; }
+        dim3 grid(64, B);
+        image_sums_kernel<<<grid, 256, 0, st>>>(img, ws, (long)HW * 3);
+    }
+    Y2_DISPATCH_DTYPE(dtype, image_apply_kernel<T><<<ew_grid((long)B * HW), 256, 0, st>>>(img, (T *)out, ws, B, HW, mode));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// optimizers, TF-1.0 Apply* semantics (train.py:70-80); g is scaled by gscale first (1/world
+// for data-parallel gradient averaging)
+// ------------------------------------------------------------------------------------------
+#define OPT_LOOP(n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+__global__ void adam_kernel(float *w, const float *g, float *m, float *v, long n, float alpha, float omb1, float omb2, float eps, float gs) {
+    OPT_LOOP(n) {
+        float gi = g[i] * gs;
+        float mi = m[i] + (gi - m[i]) * omb1;
+        float vi = v[i] + (gi * gi - v[i]) * omb2;
+        m[i] = mi;
+        v[i] = vi;
+        w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
+    }
+}
+__global__ void momentum_kernel(float *w, const float *g, float *acc, long n, float lr, float mom, float gs) {
+    OPT_LOOP(n) {
+        float a = acc[i] * mom + g[i] * gs;
+        acc[i] = a;
+        w[i] = w[i] - lr * a;
+    }
+}
+__global__ void sgd_kernel(float *w, const float *g, long n, float lr, float gs) {
+    OPT_LOOP(n) w[i] = w[i] - lr * (g[i] * gs);
+}
+__global__ void rmsprop_kernel(float *w, const float *g, float *ms, float *mom, long n, float lr, float omd, float momentum, float eps, float gs) {
+    OPT_LOOP(n) {
+        float gi = g[i] * gs;
+        float s = ms[i] + (gi * gi - ms[i]) * omd;
+        float mo = mom[i] * momentum + lr * gi / sqrtf(s + eps);
+        ms[i] = s;
+        mom[i] = mo;
+        w[i] = w[i] - mo;
+    }
+}
+__global__ void adagrad_kernel(float *w, const float *g, float *acc, long n, float lr, float gs) {
+    OPT_LOOP(n) {
+        float gi = g[i] * gs;
+        float a = acc[i] + gi * gi;
+        acc[i] = a;
+        w[i] = w[i] - lr * gi / sqrtf(a);
+    }
+}
+__global__ void adadelta_kernel(float *w, const float *g, float *acc, float *accu, long n, float lr, float rho, float eps, float gs) {
+    OPT_LOOP(n) {
+        float gi = g[i] * gs;
+        float a = acc[i] * rho + gi * gi * (1.0f - rho);
+        float u = sqrtf(accu[i] + eps) / sqrtf(a + eps) * gi;
+        accu[i] = accu[i] * rho + u * u * (1.0f - rho);
+        acc[i] = a;
+        w[i] = w[i] - lr * u;
+    }
+}
+
+extern "C" int yolo2_adam(float *w, const float *g, float *m, float *v, long n, float alpha, float beta1, float beta2, float eps, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && m && v && n > 0);
+    adam_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, m, v, n, alpha, 1.0f - beta1, 1.0f - beta2, eps, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_momentum(float *w, const float *g, float *acc, long n, float lr, float momentum, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && acc && n > 0);
+    momentum_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, acc, n, lr, momentum, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_sgd(float *w, const float *g, long n, float lr, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && n > 0);
+    sgd_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, n, lr, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_rmsprop(float *w, const float *g, float *ms, float *mom, long n, float lr, float decay, float momentum, float eps, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && ms && mom && n > 0);
+    rmsprop_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, ms, mom, n, lr, 1.0f - decay, momentum, eps, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_adagrad(float *w, const float *g, float *acc, long n, float lr, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && acc && n > 0);
+    adagrad_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, acc, n, lr, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_adadelta(float *w, const float *g, float *acc, float *acc_update, long n, float lr, float rho, float eps, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && acc && acc_update && n > 0);
+    adadelta_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, acc, acc_update, n, lr, rho, eps, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// per-tensor clip_by_norm: one block row per segment (grid.y = segment), two passes
+__global__ void seg_sumsq_kernel(const float *__restrict__ g, const long *__restrict__ seg_off, double *__restrict__ ws) {
+    const int s = blockIdx.y;
+    const long beg = seg_off[s], end = seg_off[s + 1];
+    double acc = 0.0;
+    for (long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x) {
+        double v = (double)g[i];
+        acc += v * v;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(ws + s, acc);
+}
+__global__ void seg_scale_kernel(float *__restrict__ g, const long *__restrict__ seg_off, const double *__restrict__ ws, float clip) {
+    const int s = blockIdx.y;
+    const long beg = seg_off[s], end = seg_off[s + 1];
+    const float norm = (float)sqrt(ws[s]);
+    const float scale = clip / fmaxf(norm, clip);
+    if (scale == 1.0f) return;
+    for (long i = beg + blockIdx.x * (long)blockDim.x + threadIdx.x; i < end; i += (long)gridDim.x * blockDim.x) g[i] = g[i] * scale;
+}
+extern "C" int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, double *ws, void *stream) {
+    Y2_CHECK_ARG(g && seg_off && ws && nseg > 0 && clip > 0.f);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * nseg, st) != hipSuccess) { yolo2_set_error("clip_by_norm: memset failed"); return YOLO2_E_LAUNCH; }
+    dim3 grid(64, nseg);
+    seg_sumsq_kernel<<<grid, 256, 0, st>>>(g, seg_off, ws);
+    seg_scale_kernel<<<grid, 256, 0, st>>>(g, seg_off, ws, clip);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout self-test for ds_read_b64_tr_b16 (used once on hardware to confirm the gather the
+// filter-gradient kernel assumes)
+// ------------------------------------------------------------------------------------------
+__global__ void selftest_tr16_kernel(short *out) {
+    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+    for (int i = threadIdx.x; i < 256; i += 64) lds[i] = (short)i;
+    __syncthreads();
+    s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lds + threadIdx.x * 4));
+    out[threadIdx.x * 4 + 0] = v[0];
+    out[threadIdx.x * 4 + 1] = v[1];
+    out[threadIdx.x * 4 + 2] = v[2];
+    out[threadIdx.x * 4 + 3] = v[3];
+}
+extern "C" int yolo2_selftest_tr16(short *out, void *stream) {
+    Y2_CHECK_ARG(out);
+    selftest_tr16_kernel<<<1, 64, 0, (hipStream_t)stream>>>(out);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}

@@ -1,0 +1,194 @@
+// YOLOv2 head on gfx950: decode (detect) and the per-grid-cell anchor loss, forward + backward
+// fused.  Replaces Model.__init__ / Objectives.__init__ (reference model/yolo2/__init__.py:28-94)
+// and the tf.gradients of the weighted objectives (Builder.create_objectives :114-119).
+//
+// One lane per (image, cell, anchor); the anchors of a cell sit in one power-of-two lane group so
+// the responsible-anchor selection (reduce_max over A, then exact float equality, :80-81) is a
+// wavefront butterfly shuffle -- no LDS, no atomics.  The IoU is computed in the reference's
+// operation order with FP contraction off, because `iou == max_A iou` is an exact compare.
+// The four objective sums are reduced wave -> block -> a deterministic second pass.
+#include "common.h"
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void loss_kernel(
+    const T *__restrict__ logits, int ld, const float *__restrict__ anchors, const float *__restrict__ mask,
+    const float *__restrict__ prob, const float *__restrict__ coords, const float *__restrict__ off_min,
+    const float *__restrict__ off_max, const float *__restrict__ areas, float w_best, float w_normal,
+    float w_coords, float w_prob, T *__restrict__ dlogits, float *__restrict__ partial, int B, int cell_h,
+    int cell_w, int A, int C, int LPC) {
+    const int cells = cell_h * cell_w;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long cell_id = gid / LPC;  // flat (b, cell)
+    const int a = (int)(gid % LPC);
+    const bool act = cell_id < (long)B * cells && a < A;
+    const float cnt = (float)((long)B * cells * A);
+    const int D = 5 + C;
+
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;  // iou_best, iou_normal, coords, prob partial sums
+    float iou = -INFINITY;
+    float z[5], sg[3], wh[2], sq[2], tc[4], m = 0.f;
+    const T *lp = nullptr;
+    if (act) {
+        lp = logits + cell_id * ld + a * D;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) z[k] = (float)lp[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sg[k] = sigmoidf_(z[k]);
+        wh[0] = expf(z[3]) * anchors[2 * a + 0];
+        wh[1] = expf(z[4]) * anchors[2 * a + 1];
+        const float area_p = wh[0] * wh[1];
+        const float hx = wh[0] / 2.0f, hy = wh[1] / 2.0f;
+        const float pminx = sg[1] - hx, pminy = sg[2] - hy, pmaxx = sg[1] + hx, pmaxy = sg[2] + hy;
+        sq[0] = sqrtf(wh[0] / (float)cell_w);
+        sq[1] = sqrtf(wh[1] / (float)cell_h);
+        m = mask[cell_id];
+        const float tminx = off_min[cell_id * 2], tminy = off_min[cell_id * 2 + 1];
+        const float tmaxx = off_max[cell_id * 2], tmaxy = off_max[cell_id * 2 + 1];
+        const float ix = fmaxf(fminf(pmaxx, tmaxx) - fmaxf(pminx, tminx), 0.0f);
+        const float iy = fmaxf(fminf(pmaxy, tmaxy) - fmaxf(pminy, tminy), 0.0f);
+        const float inter = ix * iy;
+        const float uni = fmaxf((areas[cell_id] + area_p) - inter, 1e-10f);
+        iou = inter / uni;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tc[k] = coords[cell_id * 4 + k];
+    }
+    // best anchor of the cell: butterfly max inside the LPC-lane group
+    float best = iou;
+    for (int o = LPC >> 1; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+
+    if (act) {
+        const float mb = m * (iou == best ? 1.0f : 0.0f);
+        const float d_iou = sg[0] - mb;
+        const float iou_dist = d_iou * d_iou;
+        s0 = mb * iou_dist;
+        s1 = (1.0f - mb) * iou_dist;
+        const float dc0 = sg[1] - tc[0], dc1 = sg[2] - tc[1], dc2 = sq[0] - tc[2], dc3 = sq[1] - tc[3];
+        s2 = mb * (dc0 * dc0) + mb * (dc1 * dc1) + mb * (dc2 * dc2) + mb * (dc3 * dc3);
+        // softmax over classes (two passes over the logits; they are L1-resident)
+        float mx = -INFINITY;
+        for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)lp[5 + k]);
+        float den = 0.f;
+        for (int k = 0; k < C; ++k) den += expf((float)lp[5 + k] - mx);
+        const float *tp = prob + cell_id * C;
+        float sp = 0.f, dot = 0.f;
+        const float gp = 2.0f * mb * w_prob / cnt;
+        for (int k = 0; k < C; ++k) {
+            float p = expf((float)lp[5 + k] - mx) / den;
+            float e = p - tp[k];
+            sp += e * e;
+            dot += (gp * e) * p;
+        }
+        s3 = mb * sp;
+        if (dlogits) {
+            T *dp = dlogits + cell_id * ld + a * D;
+            const float w_obj = w_best * mb + w_normal * (1.0f - mb);
+            dp[0] = (T)(2.0f * (sg[0] - mb) * w_obj / cnt * sg[0] * (1.0f - sg[0]));
+            dp[1] = (T)(2.0f * mb * dc0 * w_coords / cnt * sg[1] * (1.0f - sg[1]));
+            dp[2] = (T)(2.0f * mb * dc1 * w_coords / cnt * sg[2] * (1.0f - sg[2]));
+            dp[3] = (T)(2.0f * mb * dc2 * w_coords / cnt * sq[0] / 2.0f);
+            dp[4] = (T)(2.0f * mb * dc3 * w_coords / cnt * sq[1] / 2.0f);
+            for (int k = 0; k < C; ++k) {
+                float p = expf((float)lp[5 + k] - mx) / den;
+                float d = gp * (p - tp[k]);
+                dp[5 + k] = (T)(p * (d - dot));
+            }
+            if (a == 0)
+                for (int k = A * D; k < ld; ++k) dlogits[cell_id * ld + k] = (T)0.f;
+        }
+    }
+    // block reduction of the four sums
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    __shared__ float red[4][4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wave][0] = s0; red[wave][1] = s1; red[wave][2] = s2; red[wave][3] = s3; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w][threadIdx.x];
+        partial[(long)blockIdx.x * 4 + threadIdx.x] = t;
+    }
+}
+
+__global__ void loss_finalize_kernel(const float *__restrict__ partial, int nblocks, float cnt, float *__restrict__ objectives) {
+    const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;  // 4 waves, one objective each
+    double acc = 0.0;
+    for (int i = lane; i < nblocks; i += 64) acc += (double)partial[(long)i * 4 + k];
+    acc = wave_sum_d(acc);
+    if (lane == 0) objectives[k] = (float)(acc / (double)cnt);
+}
+
+static int lanes_per_cell(int A) {
+    int l = 1;
+    while (l < A) l <<= 1;
+    return l;
+}
+
+extern "C" int yolo2_loss(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
+                          const float *coords, const float *off_min, const float *off_max, const float *areas,
+                          const float *hparam, float *objectives, void *dlogits, float *ws, int B, int cell_h,
+                          int cell_w, int A, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(logits && anchors && mask && prob && coords && off_min && off_max && areas && hparam && objectives && ws);
+    Y2_CHECK_ARG(B > 0 && cell_h > 0 && cell_w > 0 && A > 0 && A <= 64 && C > 0 && ld >= A * (5 + C));
+    hipStream_t st = (hipStream_t)stream;
+    const int LPC = lanes_per_cell(A);
+    const long threads = (long)B * cell_h * cell_w * LPC;
+    const int nblocks = cdiv(threads, 256);
+    float hp[4];
+    // hparam is a host pointer: 4 weights {iou_best, iou_normal, coords, prob}
+    hp[0] = hparam[0]; hp[1] = hparam[1]; hp[2] = hparam[2]; hp[3] = hparam[3];
+    Y2_DISPATCH_DTYPE(dtype, loss_kernel<T><<<nblocks, 256, 0, st>>>((const T *)logits, ld, anchors, mask, prob, coords, off_min, off_max, areas,
+                                                                     hp[0], hp[1], hp[2], hp[3], (T *)dlogits, ws, B, cell_h, cell_w, A, C, LPC));
+    loss_finalize_kernel<<<1, 256, 0, st>>>(ws, nblocks, (float)((long)B * cell_h * cell_w * A), objectives);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// decode for detection (model/yolo2/__init__.py:50-56; calc_cell_xy model/yolo/__init__.py:29-34)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void decode_kernel(const T *__restrict__ logits, int ld, const float *__restrict__ anchors,
+                                                     float *__restrict__ conf, float *__restrict__ xy_min, float *__restrict__ xy_max,
+                                                     int *__restrict__ nan_flag, int B, int cell_h, int cell_w, int A, int C) {
+    const int cells = cell_h * cell_w;
+    const long total = (long)B * cells * A;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int a = (int)(gid % A);
+    const long cell_id = gid / A;
+    const int cell = (int)(cell_id % cells);
+    const float cx = (float)(cell % cell_w), cy = (float)(cell / cell_w);
+    const int D = 5 + C;
+    const T *lp = logits + cell_id * ld + a * D;
+    const float s_iou = sigmoidf_((float)lp[0]);
+    const float sx = sigmoidf_((float)lp[1]), sy = sigmoidf_((float)lp[2]);
+    const float w = expf((float)lp[3]) * anchors[2 * a], h = expf((float)lp[4]) * anchors[2 * a + 1];
+    const float hx = w / 2.0f, hy = h / 2.0f;
+    float o[4] = {cx + (sx - hx), cy + (sy - hy), cx + (sx + hx), cy + (sy + hy)};
+    xy_min[gid * 2] = o[0]; xy_min[gid * 2 + 1] = o[1];
+    xy_max[gid * 2] = o[2]; xy_max[gid * 2 + 1] = o[3];
+    bool bad = !(isfinite(o[0]) && isfinite(o[1]) && isfinite(o[2]) && isfinite(o[3]));
+    float mx = -INFINITY;
+    for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)lp[5 + k]);
+    float den = 0.f;
+    for (int k = 0; k < C; ++k) den += expf((float)lp[5 + k] - mx);
+    for (int k = 0; k < C; ++k) {
+        float v = s_iou * (expf((float)lp[5 + k] - mx) / den);
+        conf[gid * C + k] = v;
+        bad |= !isfinite(v);
+    }
+    if (bad && nan_flag) atomicOr(nan_flag, 1);
+}
+
+extern "C" int yolo2_head_decode(const void *logits, int ld, const float *anchors, float *conf, float *xy_min, float *xy_max,
+                                 int *nan_flag, int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(logits && anchors && conf && xy_min && xy_max);
+    Y2_CHECK_ARG(B > 0 && cell_h > 0 && cell_w > 0 && A > 0 && C > 0 && ld >= A * (5 + C));
+    const long total = (long)B * cell_h * cell_w * A;
+    Y2_DISPATCH_DTYPE(dtype, decode_kernel<T><<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const T *)logits, ld, anchors, conf, xy_min, xy_max, nan_flag, B, cell_h, cell_w, A, C));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}

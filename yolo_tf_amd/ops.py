@@ -1,0 +1,146 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (torch tensors are only device memory +
+stream plumbing here).  Used by the engine and by the per-kernel parity tests."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, dtype_code
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+def conv2d(P, F, bias, O, B, H, W, Cp, ldp, Nf, ldo, ksize):
+    call('yolo2_conv2d', ptr(P), ptr(F), ptr(bias), ptr(O), B, H, W, Cp, ldp, Nf, ldo, ksize, dtype_code(P.dtype), _stream())
+
+
+def conv2d_wgrad(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize):
+    call('yolo2_conv2d_wgrad', ptr(X), ptr(dY), ptr(dW), B, H, W, Cin, ldx, Cout, ldy, ksize, dtype_code(X.dtype), _stream())
+
+
+def filter_prep(Wt, Ffwd, Fdgr, ksize, Cin, ldcin, Cout, ldcout, dtype):
+    call('yolo2_filter_prep', ptr(Wt), ptr(Ffwd), ptr(Fdgr), ksize, Cin, ldcin, Cout, ldcout, dtype_code(dtype), _stream())
+
+
+def bn_stats(Y, mean, var, ws, M, C):
+    call('yolo2_bn_stats', ptr(Y), ptr(mean), ptr(var), ptr(ws), M, C, dtype_code(Y.dtype), _stream())
+
+
+def bn_ema(mm, mv, mean, var, C, decay):
+    call('yolo2_bn_ema', ptr(mm), ptr(mv), ptr(mean), ptr(var), C, decay, _stream())
+
+
+def bn_leaky(Y, mean, var, gamma, beta, A, M, C, lda, eps, alpha):
+    call('yolo2_bn_leaky', ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(A), M, C, lda, eps, alpha, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_bwd_reduce(dA, ldda, Y, mean, var, gamma, beta, dgamma, dbeta, ws, M, C, eps, alpha):
+    call('yolo2_bn_leaky_bwd_reduce', ptr(dA), ldda, ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta), ptr(ws),
+         M, C, eps, alpha, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_bwd_apply(dA, ldda, Y, mean, var, gamma, beta, dgamma, dbeta, dY, M, C, eps, alpha):
+    call('yolo2_bn_leaky_bwd_apply', ptr(dA), ldda, ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta), ptr(dY),
+         M, C, eps, alpha, dtype_code(Y.dtype), _stream())
+
+
+def maxpool_fwd(A, P, B, H, W, C, stride):
+    call('yolo2_maxpool_fwd', ptr(A), ptr(P), B, H, W, C, stride, dtype_code(A.dtype), _stream())
+
+
+def maxpool_bwd(A, dP, dA, B, H, W, C, stride):
+    call('yolo2_maxpool_bwd', ptr(A), ptr(dP), ptr(dA), B, H, W, C, stride, dtype_code(A.dtype), _stream())
+
+
+def reorg(x, out, B, H, W, C, ldo):
+    call('yolo2_reorg', ptr(x), ptr(out), B, H, W, C, ldo, dtype_code(x.dtype), _stream())
+
+
+def reorg_bwd(dout, ldd, din, B, H, W, C):
+    call('yolo2_reorg_bwd', ptr(dout), ldd, ptr(din), B, H, W, C, dtype_code(din.dtype), _stream())
+
+
+def copy_channels(src, lds, dst, ldd, M, C):
+    call('yolo2_copy_channels', ptr(src), lds, ptr(dst), ldd, M, C, dtype_code(src.dtype), _stream())
+
+
+def add_inplace(dst, src, n):
+    call('yolo2_add_inplace', ptr(dst), ptr(src), n, dtype_code(dst.dtype), _stream())
+
+
+def bias_grad(dY, ld, dbias, ws, M, C):
+    call('yolo2_bias_grad', ptr(dY), ld, ptr(dbias), ptr(ws), M, C, dtype_code(dY.dtype), _stream())
+
+
+def image_prep(img, out, ws, B, HW, mode):
+    call('yolo2_image_prep', ptr(img), ptr(out), ptr(ws), B, HW, mode, dtype_code(out.dtype), _stream())
+
+
+def head_decode(logits, ld, anchors, conf, xy_min, xy_max, nan_flag, B, ch, cw, A, C):
+    call('yolo2_head_decode', ptr(logits), ld, ptr(anchors), ptr(conf), ptr(xy_min), ptr(xy_max), ptr(nan_flag), B, ch, cw, A, C,
+         dtype_code(logits.dtype), _stream())
+
+
+def loss(logits, ld, anchors, labels, hparam, objectives, dlogits, ws, B, ch, cw, A, C):
+    """labels: 6 device f32 tensors (mask, prob, coords, off_min, off_max, areas); hparam: 4 host floats
+    in the order iou_best, iou_normal, coords, prob."""
+    hp = (ctypes.c_float * 4)(*[float(v) for v in hparam])
+    mask, prob, coords, omin, omax, areas = labels
+    call('yolo2_loss', ptr(logits), ld, ptr(anchors), ptr(mask), ptr(prob), ptr(coords), ptr(omin), ptr(omax), ptr(areas), hp,
+         ptr(objectives), ptr(dlogits), ptr(ws), B, ch, cw, A, C, dtype_code(logits.dtype), _stream())
+
+
+def loss_ws_floats(B, cells, A):
+    lpc = 1
+    while lpc < A:
+        lpc *= 2
+    return 4 * ((B * cells * lpc + 255) // 256) + 4
+
+
+def nms(conf, xy_min, xy_max, order, ws, B, N, C, thr, thr_iou):
+    call('yolo2_nms', ptr(conf), ptr(xy_min), ptr(xy_max), ptr(order), ptr(ws), B, N, C, thr, thr_iou, _stream())
+
+
+def adam(w, g, m, v, n, alpha, b1, b2, eps, gscale=1.0):
+    call('yolo2_adam', ptr(w), ptr(g), ptr(m), ptr(v), n, alpha, b1, b2, eps, gscale, _stream())
+
+
+def momentum(w, g, acc, n, lr, mom, gscale=1.0):
+    call('yolo2_momentum', ptr(w), ptr(g), ptr(acc), n, lr, mom, gscale, _stream())
+
+
+def sgd(w, g, n, lr, gscale=1.0):
+    call('yolo2_sgd', ptr(w), ptr(g), n, lr, gscale, _stream())
+
+
+def rmsprop(w, g, ms, mom, n, lr, decay, momentum_, eps, gscale=1.0):
+    call('yolo2_rmsprop', ptr(w), ptr(g), ptr(ms), ptr(mom), n, lr, decay, momentum_, eps, gscale, _stream())
+
+
+def adagrad(w, g, acc, n, lr, gscale=1.0):
+    call('yolo2_adagrad', ptr(w), ptr(g), ptr(acc), n, lr, gscale, _stream())
+
+
+def adadelta(w, g, acc, accu, n, lr, rho, eps, gscale=1.0):
+    call('yolo2_adadelta', ptr(w), ptr(g), ptr(acc), ptr(accu), n, lr, rho, eps, gscale, _stream())
+
+
+def clip_by_norm(g, seg_off, nseg, clip, ws):
+    call('yolo2_clip_by_norm', ptr(g), ptr(seg_off), nseg, clip, ptr(ws), _stream())
+
+
+def selftest_tr16():
+    out = torch.zeros(256, dtype=torch.int16, device='cuda')
+    call('yolo2_selftest_tr16', ptr(out), _stream())
+    torch.cuda.synchronize()
+    return out.cpu().numpy().reshape(64, 4)
+
+
+def set_wgrad_variant(v):
+    _lib.load().yolo2_debug_set_wgrad_variant(int(v))
