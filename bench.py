@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""bench.py -- training throughput of the MI355X YOLOv2 hot path on BASELINE.json's metric:
+img/s training Darknet-19 YOLOv2 VOC-20 416x416 bf16, batch 16 per GPU (configs[1]); weak scaling
+over N GPUs of one node (one process per GPU, RCCL gradient all-reduce overlapped with backward).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = per-image standardisation -> forward (batch-stat BN) -> YOLOv2 loss fwd+bwd -> backward
+-> gradient all-reduce (N>1) -> Adam, on a synthetic batch that is already resident in HBM.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (conv_igemm_kernel<bf16,128,2>: 3x3/1x1 forward + data-gradient
+                convolutions with > 64 filters) -- algorithmic FLOPs / HIP-event time of its
+                launches inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the NumPy oracle's training step (oracle/yolo2_ref.py, a port: TF-1.0 cannot run
+                here) on one 416x416 image on the host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_MATRIX_PEAK_TFLOPS = 157.3
+TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
+
+
+class KernelTimer(object):
+    """HIP events around every launch of the dominant kernel, on the stream it is launched on."""
+
+    def __init__(self):
+        self.pairs = []
+        self.flops = []
+        self.enabled = False
+        self._cur = None
+
+    def start(self, flops):
+        if not self.enabled:
+            return
+        a = torch.cuda.Event(enable_timing=True)
+        a.record(torch.cuda.current_stream())
+        self._cur = (a, flops)
+
+    def stop(self):
+        if self._cur is None:
+            return
+        b = torch.cuda.Event(enable_timing=True)
+        b.record(torch.cuda.current_stream())
+        self.pairs.append((self._cur[0], b))
+        self.flops.append(self._cur[1])
+        self._cur = None
+
+    def summary(self):
+        if not self.pairs:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.pairs]
+        total_ms = float(sum(ms))
+        return {'launches': len(ms), 'avg_ms': total_ms / len(ms), 'total_ms': total_ms,
+                'tflops': float(sum(self.flops)) / (total_ms * 1e-3) / 1e12, 'flop_per_launch': float(sum(self.flops)) / len(ms)}
+
+
+def make_builder(inference, names, size, training, basedir):
+    from yolo_tf_amd import utils
+    from yolo_tf_amd.model import yolo2
+    cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo2', '%s-%d.ini' % (inference, names))], basedir)
+    cfg.set('cache', 'names', os.path.join(ROOT, cfg.get('cache', 'names')))
+    cfg.set('yolo2', 'anchors', os.path.join(ROOT, cfg.get('yolo2', 'anchors')))
+    cfg.set('yolo2', 'width', str(size))
+    cfg.set('yolo2', 'height', str(size))
+    utils.ensure_names(cfg)
+    b = yolo2.Builder(None, cfg)
+    b(None, training=training)
+    if training:
+        b.create_objectives()
+    return b, cfg
+
+
+def cpu_baseline(names, size, budget_s=30.0):
+    """Times the NumPy oracle's train step (forward + loss + backward + Adam) on ONE image of the same
+    workload shape.  Test infrastructure used as the reported CPU baseline; never on the product path."""
+    from oracle import yolo2_ref as R
+    from yolo_tf_amd.utils import data
+    anchors = np.loadtxt(os.path.join(ROOT, 'config', 'yolo2', 'anchors', 'voc.tsv' if names == 20 else 'coco.tsv'), delimiter='\t', skiprows=1)
+    spec = R.darknet_spec(names, len(anchors))
+    params = R.init_params(spec, seed=0)
+    rng = np.random.RandomState(0)
+    cells = size // 32
+    hp = {'prob': 1., 'iou_best': 5., 'iou_normal': 1., 'coords': 1.}
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    n, t_total = 0, 0.0
+    while n < 1 or (t_total < 10.0 and t_total / n * (n + 1) < budget_s):
+        x = rng.randn(1, size, size, 3).astype(np.float32)
+        labels = data.synthetic_batch(1, names, cells, cells, seed=n)
+        t0 = time.time()
+        R.train_step(spec, params, {}, x, labels, names, anchors, hp, 1e-6, 0)
+        t_total += time.time() - t0
+        n += 1
+    return {'value': n / t_total, 'unit': 'img/s', 'cores': int(threads), 'kind': 'port',
+            'sample': '%d single-image 416x416 Darknet-19 training steps (fwd+loss+bwd+Adam) of oracle/yolo2_ref.py, NumPy/BLAS f32, %.1f s; '
+                      'CPU restatement of reference semantics (TensorFlow 1.0 unavailable)' % (n, t_total),
+            'host_cores': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='images per GPU (weak scaling)')
+    ap.add_argument('--names', type=int, default=20, choices=[20, 80])
+    ap.add_argument('--size', type=int, default=416)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--detect', action='store_true', help='also report batch-256 detect p50/p99 (config #5) on rank 0')
+    args = ap.parse_args()
+
+    from yolo_tf_amd.parallel import init_distributed
+    import torch.distributed as dist
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    torch.cuda.set_device(local_rank)
+
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    basedir = tempfile.mkdtemp(prefix='yolo_bench_%d_' % rank)
+    builder, cfg = make_builder('darknet', args.names, args.size, True, basedir)
+    sess = TrainSession(builder, args.batch, dtype=args.dtype, optimizer='adam', learning_rate=1e-6, seed=0, world_size=world,
+                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'))
+    cells = args.size // 32
+    gen = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    images = torch.rand(args.batch, args.size, args.size, 3, device='cuda', generator=gen) * 255.0
+    sess.upload_labels(data.synthetic_batch(args.batch, args.names, cells, cells, seed=4321 + rank))
+    timer = None if args.no_kernel_timer else KernelTimer()
+    sess.engine.kernel_timer = timer
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sess.step(images)
+    torch.cuda.synchronize()
+    barrier()
+    if timer:
+        timer.enabled = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sess.step(images)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if timer:
+        timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = sess.fetch()
+
+    if rank == 0:
+        total_images = world * args.batch * args.steps
+        value = total_images / elapsed
+        gflop = TRAIN_GFLOP_PER_IMG[args.names] * (args.size / 416.0) ** 2
+        peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MATRIX_PEAK_TFLOPS
+        out = {
+            'metric': 'train_throughput', 'value': value, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Darknet-19 YOLOv2 VOC-%d %dx%d training step (standardise+fwd+loss+bwd+Adam), batch %d per GPU (BASELINE configs[1])'
+                                   % (args.names, args.size, args.size, args.batch),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)'},
+            'whole_step_tflops': value * gflop / 1e3,
+            'whole_step_frac_of_mfma_peak': value * gflop / 1e3 / peak / world,
+            'total_loss': loss['total_loss'],
+        }
+        ks = timer.summary() if timer else None
+        if ks:
+            out['roofline'] = {'bound': 'mfma', 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak,
+                               'traffic': None, 'kernel': 'conv_igemm_kernel<%s,128,2> (forward + data-gradient convolutions, Nf > 64)' % args.dtype,
+                               'launches': ks['launches'], 'avg_launch_ms': ks['avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
+                               'share_of_step_time': ks['total_ms'] / (elapsed * 1e3)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.names, args.size)
+        if args.detect and world == 1:
+            out['detect'] = detect_latency(args, basedir)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def detect_latency(args, basedir, batch=256, iters=30):
+    """BASELINE configs[4]: batch-256 416x416 detect (forward + decode + on-GPU NMS), p50/p99 latency."""
+    from yolo_tf_amd.session import DetectSession
+    b, _ = make_builder('darknet', args.names, args.size, False, basedir)
+    sess = DetectSession(b, batch, dtype=args.dtype, seed=0)
+    images = torch.rand(batch, args.size, args.size, 3, device='cuda') * 255.0
+    for _ in range(3):
+        sess.detect(images, 0.3, 0.4)
+    torch.cuda.synchronize()
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        sess.detect(images, 0.3, 0.4)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    return {'batch': batch, 'p50_ms': times[len(times) // 2], 'p99_ms': times[min(len(times) - 1, int(len(times) * 0.99))],
+            'img_per_s': batch / (times[len(times) // 2] * 1e-3), 'iters': iters}
+
+
+if __name__ == '__main__':
+    main()

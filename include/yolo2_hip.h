@@ -69,9 +69,10 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
 /* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 2*C doubles (any content) */
 int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C,
                    int dtype, void *stream);
-/* moving -= (1-decay)*(moving-batch)   (assign_moving_average, decay 0.999) */
+/* moving -= f32(1-decay)*(moving-batch)   (assign_moving_average, decay 0.999; 1-decay is formed in
+ * double and then rounded, as TF's Python side does) */
 int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var,
-                 int C, float decay, void *stream);
+                 int C, double decay, void *stream);
 /* A[m,c] = leaky(gamma*(Y-mean)/sqrt(var+eps)+beta); A has pixel stride lda (concat target) */
 int yolo2_bn_leaky(const void *Y, const float *mean, const float *var, const float *gamma,
                    const float *beta, void *A, long M, int C, int lda, float eps, float alpha,

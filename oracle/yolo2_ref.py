@@ -486,8 +486,8 @@ def adam_step(w, g, m, v, lr, t, beta1=0.9, beta2=0.999, eps=1e-8):
     m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= alpha*m/(sqrt(v)+eps)  (eps outside the sqrt)."""
     ty = w.dtype.type
     alpha = ty(lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t))
-    m = m + (g - m) * ty(1 - beta1)
-    v = v + (g * g - v) * ty(1 - beta2)
+    m = m + (g - m) * (ty(1) - ty(beta1))        # (T(1) - beta1) is formed in T by the TF kernel
+    v = v + (g * g - v) * (ty(1) - ty(beta2))
     w = w - (m * alpha) / (np.sqrt(v) + ty(eps))
     return w, m, v
 
@@ -506,7 +506,7 @@ def gd_step(w, g, lr):
 def rmsprop_step(w, g, ms, mom, lr, decay=0.9, momentum=0.0, eps=1e-10):
     """[TF-sem] ApplyRMSProp: ms += (g^2-ms)(1-decay); mom = mom*momentum + lr*g/sqrt(ms+eps); w -= mom."""
     ty = w.dtype.type
-    ms = ms + (g * g - ms) * ty(1 - decay)
+    ms = ms + (g * g - ms) * (ty(1) - ty(decay))
     mom = mom * ty(momentum) + ty(lr) * g / np.sqrt(ms + ty(eps))
     return w - mom, ms, mom
 
@@ -521,9 +521,9 @@ def adadelta_step(w, g, acc, acc_update, lr, rho=0.95, eps=1e-8):
     """[TF-sem] ApplyAdadelta: acc = rho*acc+(1-rho)g^2; upd = sqrt(acc_update+eps)/sqrt(acc+eps)*g;
     acc_update = rho*acc_update+(1-rho)upd^2; w -= lr*upd."""
     ty = w.dtype.type
-    acc = acc * ty(rho) + g * g * ty(1 - rho)
+    acc = acc * ty(rho) + g * g * (ty(1) - ty(rho))
     upd = np.sqrt(acc_update + ty(eps)) / np.sqrt(acc + ty(eps)) * g
-    acc_update = acc_update * ty(rho) + upd * upd * ty(1 - rho)
+    acc_update = acc_update * ty(rho) + upd * upd * (ty(1) - ty(rho))
     return w - ty(lr) * upd, acc, acc_update
 
 

@@ -1,0 +1,203 @@
+"""End-to-end parity on the MI355X: the traced Darknet-19 / Tiny YOLOv2 graphs through the engine
+(forward, loss, backward, Adam, BN moving averages, detect + NMS) vs the CPU oracle on identical
+weights and inputs.  Small spatial size so the NumPy oracle finishes in seconds; full-size
+(416x416, batch 16) runs are checked through size-independent properties."""
+import ctypes
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo2_ref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = {'prob': 1., 'iou_best': 5., 'iou_normal': 1., 'coords': 1.}
+
+
+def make_builder(inference, names, size, training, basedir):
+    from yolo_tf_amd import utils
+    from yolo_tf_amd.model import yolo2
+    cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo2', '%s-%d.ini' % (inference, names))], basedir)
+    cfg.set('cache', 'names', os.path.join(ROOT, cfg.get('cache', 'names')))
+    cfg.set('yolo2', 'anchors', os.path.join(ROOT, cfg.get('yolo2', 'anchors')))
+    cfg.set('yolo2', 'width', str(size))
+    cfg.set('yolo2', 'height', str(size))
+    utils.ensure_names(cfg)
+    b = yolo2.Builder(None, cfg)
+    b(None, training=training)
+    if training:
+        b.create_objectives()
+    return b, cfg
+
+
+def rel(got, ref):
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
+def strip(params, scope):
+    return {k[len(scope) + 1:]: v for k, v in params.items()}
+
+
+@pytest.fixture(scope='module')
+def basedir():
+    with tempfile.TemporaryDirectory() as d:
+        yield d
+
+
+@pytest.mark.parametrize('inference,size,dtype', [('darknet', 64, 'f32'), ('tiny', 64, 'f32'), ('darknet', 96, 'f32'),
+                                                  ('darknet', 64, 'bf16'), ('tiny', 64, 'bf16')])
+def test_train_step_matches_oracle(basedir, inference, size, dtype):
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B, classes = 2, 20
+    b, cfg = make_builder(inference, classes, size, True, basedir)
+    sess = TrainSession(b, B, dtype=dtype, optimizer='adam', learning_rate=1e-3, seed=3)
+    scope = 'yolo2_' + inference
+    params0 = strip(sess.engine.get_variables(), scope)
+    # non-trivial BN parameters so that beta/gamma gradients are exercised
+    rng = np.random.RandomState(0)
+    for k in list(params0):
+        if k.endswith('gamma'):
+            params0[k] = (rng.rand(*params0[k].shape) + 0.5).astype(np.float32)
+        if k.endswith(('beta', 'biases')):
+            params0[k] = (rng.randn(*params0[k].shape) * 0.1).astype(np.float32)
+    sess.engine.set_variables({scope + '/' + k: v for k, v in params0.items()})
+    cells = size // 32
+    images = rng.uniform(0, 255, (B, size, size, 3)).astype(np.float32)
+    labels = data.synthetic_batch(B, classes, cells, cells, seed=7)
+    sess.step(torch.from_numpy(images).cuda(), labels)
+    got = sess.fetch()
+    e = sess.engine
+    logits = e.act[e.output()][0].float().cpu().numpy().reshape(B, cells, cells, -1)[..., :b.model.inputs.c]
+    grads = strip(e.get_gradients(), scope)
+    params1 = strip(e.get_variables(), scope)
+
+    spec = R.SPECS[inference](classes, len(b.anchors))
+    x = np.stack([R.per_image_standardization(i) for i in images]).astype(np.float32)
+    new_params, _, info = R.train_step(spec, params0, {}, x, labels, classes, b.anchors, HP, 1e-3, 0)
+
+    f32 = dtype == 'f32'
+    tol_out, tol_loss, tol_grad = (1e-4, 1e-4, 2e-3) if f32 else (6e-2, 5e-2, 0.25)
+    r = rel(logits, info['net'])
+    assert r <= tol_out, 'logits rel err %.3e' % r
+    for k in R.OBJECTIVE_KEYS:
+        assert abs(got[k] - info['objectives'][k]) <= tol_loss * abs(info['objectives'][k]) + 1e-7, (k, got[k], info['objectives'][k])
+    assert abs(got['total_loss'] - info['loss']) <= tol_loss * abs(info['loss'])
+    worst = max((rel(grads[k], info['grads'][k]), k) for k in grads)
+    assert worst[0] <= tol_grad, 'worst gradient rel err %.3e at %s' % worst
+    if f32:
+        # Adam moves every weight by ~lr at step 1 regardless of gradient magnitude, so compare the update direction
+        for k in ('conv0/weights', 'conv/weights', 'conv/biases'):
+            du_g, du_r = params1[k] - params0[k], new_params[k] - params0[k]
+            agree = np.mean(np.sign(du_g) == np.sign(du_r))
+            assert agree > 0.98, (k, agree)
+        for k in params0:
+            if k.endswith(('moving_mean', 'moving_variance')):
+                assert rel(params1[k], new_params[k]) <= 1e-4, k
+
+
+def test_detect_matches_oracle(basedir):
+    from yolo_tf_amd.session import DetectSession
+    B, classes, size = 2, 20, 96
+    b, _ = make_builder('darknet', classes, size, False, basedir)
+    sess = DetectSession(b, B, dtype='f32', seed=5)
+    scope = 'yolo2_darknet'
+    params = strip(sess.engine.get_variables(), scope)
+    rng = np.random.RandomState(1)
+    for k in list(params):          # moving stats away from their init so inference-mode BN is exercised
+        if k.endswith('moving_mean'):
+            params[k] = (rng.randn(*params[k].shape) * 0.05).astype(np.float32)
+        if k.endswith('moving_variance'):
+            params[k] = (rng.rand(*params[k].shape) * 0.5 + 0.05).astype(np.float32)
+    params['conv/biases'] = (rng.randn(*params['conv/biases'].shape)).astype(np.float32)
+    sess.engine.set_variables({scope + '/' + k: v for k, v in params.items()})
+    images = rng.uniform(0, 255, (B, size, size, 3)).astype(np.float32)
+    conf, mn, mx = [t.clone() for t in sess.run(torch.from_numpy(images).cuda())]
+    x = np.stack([R.per_image_standardization(i) for i in images]).astype(np.float32)
+    net, _ = R.network_forward(R.darknet_spec(classes, 5), params, x, training=False)
+    m = R.model_decode(net, classes, b.anchors, training=False)
+    cells = (size // 32) ** 2
+    assert rel(conf.cpu().numpy().reshape(B, cells, 5, classes), m['conf']) <= 1e-4
+    assert rel(mn.cpu().numpy().reshape(B, cells, 5, 2), m['xy_min']) <= 1e-4
+    assert rel(mx.cpu().numpy().reshape(B, cells, 5, 2), m['xy_max']) <= 1e-4
+    # NMS on the GPU-produced scores must equal the C oracle on the very same scores, bit for bit
+    thr = float(np.percentile(conf.cpu().numpy(), 90))
+    order = sess.nms(thr, 0.4).cpu().numpy()
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libnms_ref.so'))
+    P = ctypes.POINTER(ctypes.c_float)
+    for i in range(B):
+        c = conf[i].cpu().numpy().copy()
+        o = np.zeros(c.shape[0], np.int64)
+        lib.nms_ref(c.ctypes.data_as(P), mn[i].cpu().numpy().ctypes.data_as(P), mx[i].cpu().numpy().ctypes.data_as(P), ctypes.c_long(c.shape[0]),
+                    ctypes.c_long(classes), ctypes.c_float(thr), ctypes.c_float(0.4), o.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
+        assert np.array_equal(sess.conf[i].cpu().numpy(), c)
+        assert np.array_equal(order[i], o)
+
+
+def test_postprocess_dropin_contract(golden_dir):
+    """utils.postprocess.non_max_suppress: same signature, in-place mutation, returned views and order."""
+    from yolo_tf_amd.utils import postprocess
+    g = np.load(os.path.join(golden_dir, 'nms.npz'))
+    for case in ('sparse20', 'ties', 'identical_ties'):
+        conf = g[case + '/conf_in'].copy()
+        mn, mx = g[case + '/xy_min'], g[case + '/xy_max']
+        boxes = postprocess.non_max_suppress(conf, mn, mx, float(g[case + '/thr']), float(g[case + '/thr_iou']))
+        assert np.array_equal(conf, g[case + '/conf_out'])                     # caller's array mutated
+        n, C = conf.shape[0] * conf.shape[1], conf.shape[2]
+        flat = conf.reshape(n, C)
+        for (c_row, b_min, b_max), idx in zip(boxes, g[case + '/order']):
+            assert np.shares_memory(c_row, conf) and np.array_equal(c_row, flat[idx])
+            assert np.array_equal(b_min, mn.reshape(n, 2)[idx]) and np.array_equal(b_max, mx.reshape(n, 2)[idx])
+
+
+def test_full_size_training_properties(basedir):
+    """BASELINE config #2 shape (Darknet-19, VOC-20, 416x416, batch 16, bf16): finite loss that goes
+    down over a few Adam steps on a fixed batch, BN moving averages move, padding lanes stay zero."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B = 16
+    b, _ = make_builder('darknet', 20, 416, True, basedir)
+    sess = TrainSession(b, B, dtype='bf16', optimizer='adam', learning_rate=1e-4, seed=0)
+    g = torch.Generator(device='cuda').manual_seed(1234)
+    images = torch.rand(B, 416, 416, 3, device='cuda', generator=g) * 255
+    sess.upload_labels(data.synthetic_batch(B, 20, 13, 13, seed=4321))
+    losses = []
+    for _ in range(6):
+        sess.step(images)
+        losses.append(sess.fetch()['total_loss'])
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    e = sess.engine
+    out = e.act[e.output()][0].float().reshape(B, 13, 13, 128)
+    assert torch.all(out[..., 125:] == 0)
+    assert float(e.var['yolo2_darknet/conv0/BatchNorm/moving_variance'].sub(1).abs().max()) > 0
+    assert torch.isfinite(e.params).all() and torch.isfinite(e.grads).all()
+
+
+def test_full_size_detect_batch_properties(basedir):
+    """BASELINE config #5 shape (batch-256 detect + on-GPU NMS is benchmarked; here batch 32):
+    NMS is idempotent, survivors per class are sorted and mutually below the IoU threshold."""
+    from yolo_tf_amd.session import DetectSession
+    B = 32
+    b, _ = make_builder('darknet', 20, 416, False, basedir)
+    sess = DetectSession(b, B, dtype='bf16', seed=0)
+    images = torch.rand(B, 416, 416, 3, device='cuda') * 255
+    conf, mn, mx = sess.run(images)
+    thr = float(torch.quantile(conf.flatten()[:1000000], 0.98))
+    before = conf.clone()
+    sess.nms(thr, 0.4)
+    once = sess.conf.clone()
+    assert torch.all((once == before) | (once == 0))
+    sess.nms(thr, 0.4)
+    assert torch.equal(sess.conf, once)                       # idempotent
+    c = once[0].cpu().numpy()
+    mnn, mxx = mn[0].cpu().numpy(), mx[0].cpu().numpy()
+    for k in range(3):
+        keep = np.where(c[:, k] > thr)[0]
+        for i in keep:
+            for j in keep:
+                if i < j:
+                    assert R.iou(mnn[i], mxx[i], mnn[j], mxx[j]) < np.float32(0.4)

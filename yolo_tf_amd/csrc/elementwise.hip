@@ -196,9 +196,9 @@ __global__ void bn_ema_kernel(float *mm, float *mv, const float *mean, const flo
         mv[c] = mv[c] - (mv[c] - var[c]) * one_minus_decay;
     }
 }
-extern "C" int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var, int C, float decay, void *stream) {
+extern "C" int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var, int C, double decay, void *stream) {
     Y2_CHECK_ARG(moving_mean && moving_var && mean && var && C > 0);
-    bn_ema_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(moving_mean, moving_var, mean, var, C, 1.0f - decay);
+    bn_ema_kernel<<<cdiv(C, 256), 256, 0, (hipStream_t)stream>>>(moving_mean, moving_var, mean, var, C, (float)(1.0 - decay));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

@@ -1,0 +1,282 @@
+"""Executes a ``graph.Graph`` on one MI355X through the C-ABI kernels.
+
+Plays the role of the TF-1 session + tf.gradients + optimizer.apply_gradients in the reference
+(train.py:109-145 builds them; slim.learning.train runs ``sess.run(train_op)``): it owns the
+device buffers (flat f32 parameter / gradient / optimizer-state arenas, activation and
+activation-gradient buffers in the compute dtype, prepared filter layouts) and launches the HIP
+kernels for forward, the YOLOv2 loss, backward and the update on the current HIP stream.
+
+Memory layout decisions (288 GB HBM: nothing is recomputed, nothing is re-allocated per step):
+  * all trainable variables live in ONE flat f32 buffer in REVERSE creation order, gradients in a
+    twin buffer: the optimizer is one launch, and the data-parallel all-reduce works on contiguous
+    ranges that complete front-to-back as backward proceeds (parallel.GradReducer).
+  * activations are NHWC with a pixel stride padded to 8 channels; tf.concat operands alias channel
+    slices of the concat buffer (producers write in place, no copy kernel).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .graph import pad8
+
+BN_EPS = 1e-5        # slim.batch_norm(epsilon=1e-5)   model/yolo2/inference.py:63
+BN_DECAY = 0.999     # [TF-sem] slim.batch_norm default decay
+LEAKY_ALPHA = 0.1    # model/yolo/function.py:21
+
+_DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f32': torch.float32, 'float32': torch.float32}
+
+
+class Engine(object):
+    def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('yolo_tf_amd.Engine needs an MI355X (no CPU path exists)')
+        ops._lib.load()
+        self.graph = graph
+        self.B = int(batch_size)
+        self.dtype = _DTYPES[dtype] if isinstance(dtype, str) else dtype
+        self.training = training
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self._alloc_variables()
+        self._alloc_activations()
+        self.init_variables(seed)
+        self._filters_dirty = True
+        self.kernel_timer = None     # optional bench.KernelTimer: HIP events around the dominant conv kernel
+
+    # ---------------------------------------------------------------- variables
+    def _alloc_variables(self):
+        g = self.graph
+        train = list(reversed(g.trainable()))
+        other = [v for v in g.variables.values() if not v.trainable]
+        self.param_offsets = {}
+        off = 0
+        for v in train:
+            self.param_offsets[v.name] = (off, v.size)
+            off += (v.size + 3) // 4 * 4         # keep every variable 16-byte aligned
+        self.n_params = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device) if self.training else None
+        self.state_offsets = {}
+        off = 0
+        for v in other:
+            self.state_offsets[v.name] = (off, v.size)
+            off += (v.size + 3) // 4 * 4
+        self.state = torch.zeros(max(off, 4), dtype=torch.float32, device=self.device)
+        self.var = {}
+        self.gvar = {}
+        for name, (o, n) in self.param_offsets.items():
+            self.var[name] = self.params[o:o + n]
+            if self.training:
+                self.gvar[name] = self.grads[o:o + n]
+        for name, (o, n) in self.state_offsets.items():
+            self.var[name] = self.state[o:o + n]
+        # per-tensor segments (for clip_by_norm) in buffer order
+        segs = sorted(self.param_offsets.values())
+        self.seg_off = torch.tensor([s[0] for s in segs] + [self.n_params], dtype=torch.int64, device=self.device)
+        self.n_seg = len(segs)
+
+    def init_variables(self, seed=0):
+        """[TF-sem] slim initialisers, seeded (the reference parses --seed but never uses it, train.py:161)."""
+        rng = np.random.RandomState(seed)
+        for v in self.graph.variables.values():
+            self.var[v.name].copy_(torch.from_numpy(v.init(rng, v.shape).reshape(-1)))
+        self._filters_dirty = True
+
+    def get_variables(self):
+        torch.cuda.synchronize()
+        return {v.name: self.var[v.name].cpu().numpy().reshape(v.shape) for v in self.graph.variables.values()}
+
+    def set_variables(self, values, strict=True):
+        for v in self.graph.variables.values():
+            if v.name in values:
+                a = np.asarray(values[v.name], np.float32)
+                assert a.shape == v.shape, (v.name, a.shape, v.shape)
+                self.var[v.name].copy_(torch.from_numpy(np.ascontiguousarray(a).reshape(-1)))
+            elif strict:
+                raise KeyError(v.name)
+        self._filters_dirty = True
+
+    def get_gradients(self):
+        torch.cuda.synchronize()
+        return {v.name: self.gvar[v.name].cpu().numpy().reshape(v.shape) for v in self.graph.trainable()}
+
+    # ---------------------------------------------------------------- activations
+    def _alloc_activations(self):
+        B, T, dev = self.B, self.dtype, self.device
+        self.act, self.gact = {}, {}
+        roots = {}
+        for t in self.graph.tensors:
+            if t.base is None:
+                roots[t] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
+        groots = {}
+        if self.training:
+            for t in self.graph.tensors:
+                if t.base is None and t not in self.graph.inputs.values():
+                    groots[t] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
+        for t in self.graph.tensors:
+            r, off, ld = t.storage()
+            self.act[t] = (roots[r][off:], ld)
+            if r in groots:
+                self.gact[t] = (groots[r][off:], ld)
+        self.conv = {}
+        max_y = 0
+        max_c = 8
+        for op in self.graph.ops:
+            if op['kind'] != 'conv':
+                continue
+            k, cin, cout = op['ksize'], op['cin'], op['cout']
+            cp, ldy = pad8(cin), pad8(cout)
+            st = {'Ffwd': torch.zeros(cout * k * k * cp, dtype=T, device=dev)}
+            if self.training and op['x'] not in self.graph.inputs.values():
+                st['Fdgr'] = torch.zeros(cin * k * k * ldy, dtype=T, device=dev)
+            if op['bn']:
+                st['mean'] = torch.zeros(cout, dtype=torch.float32, device=dev)
+                st['var'] = torch.ones(cout, dtype=torch.float32, device=dev)
+            self.conv[op['name']] = st
+            max_y = max(max_y, B * op['out'].h * op['out'].w * ldy)
+            max_c = max(max_c, ldy)
+        self.ws = torch.zeros(2 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)
+        if self.training:
+            self.dy_scratch = torch.zeros(max_y, dtype=T, device=dev)
+            self.tmp_grad = {}
+        self.img = None
+
+    # ---------------------------------------------------------------- helpers
+    def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k):
+        """yolo2_conv2d launch; when a timer is attached, launches that take the 128-wide filter tile
+        (Nf > 64: the kernel that carries ~2/3 of the training FLOPs) are bracketed by HIP events.
+        ``real_k`` = unpadded reduction length, for the algorithmic FLOP count."""
+        t = self.kernel_timer if Nf > 64 else None
+        if t is not None:
+            t.start(2.0 * self.B * H * W * Nf * real_k)
+        ops.conv2d(P, F, bias, O, self.B, H, W, Cp, ldp, Nf, ldo, k)
+        if t is not None:
+            t.stop()
+
+    def _prepare_filters(self):
+        if not self._filters_dirty:
+            return
+        for op in self.graph.ops:
+            if op['kind'] != 'conv':
+                continue
+            st = self.conv[op['name']]
+            ops.filter_prep(self.var[op['weights'].name], st['Ffwd'], st.get('Fdgr'), op['ksize'], op['cin'], pad8(op['cin']),
+                            op['cout'], pad8(op['cout']), self.dtype)
+        self._filters_dirty = False
+
+    def set_images(self, images, mode=0):
+        """images: f32 [B,H,W,3] device tensor (0..255 for mode 0/1).  mode 0 = per_image_standardization
+        (train.py:103 / detect.py `std`), 1 = /255 (detect.py `darknet`), 2 = already preprocessed."""
+        (inp,) = self.graph.inputs.values()
+        assert images.dtype == torch.float32 and images.is_cuda and images.numel() == self.B * inp.h * inp.w * 3
+        self.img = images.contiguous()
+        ops.image_prep(self.img, self.act[inp][0], self.ws, self.B, inp.h * inp.w, mode)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self):
+        self._prepare_filters()
+        B = self.B
+        for op in self.graph.ops:
+            kind = op['kind']
+            if kind == 'conv':
+                x, out = op['x'], op['out']
+                xb, ldx = self.act[x]
+                st = self.conv[op['name']]
+                M = B * out.h * out.w
+                if op['bn']:
+                    yb, ldy = self.act[op['y']]
+                    self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'])
+                    gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
+                    if self.training:
+                        ops.bn_stats(yb, st['mean'], st['var'], self.ws, M, op['cout'])
+                        ops.bn_ema(self.var[op['moving_mean'].name], self.var[op['moving_variance'].name], st['mean'], st['var'],
+                                   op['cout'], BN_DECAY)
+                        mean, var = st['mean'], st['var']
+                    else:
+                        mean, var = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
+                    ob, ldo = self.act[out]
+                    ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
+                else:
+                    ob, ldo = self.act[out]
+                    self._conv(xb, st['Ffwd'], self.var[op['biases'].name], ob, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], op['ksize'] ** 2 * op['cin'])
+            elif kind == 'pool':
+                x, out = op['x'], op['out']
+                assert self.act[x][1] == x.c and self.act[out][1] == out.c
+                ops.maxpool_fwd(self.act[x][0], self.act[out][0], B, x.h, x.w, x.c, op['stride'])
+            elif kind == 'reorg':
+                x, out = op['x'], op['out']
+                assert self.act[x][1] == x.c
+                ops.reorg(self.act[x][0], self.act[out][0], B, x.h, x.w, x.c, self.act[out][1])
+            elif kind == 'concat':
+                pass
+            else:
+                raise ValueError(kind)
+
+    # ---------------------------------------------------------------- backward
+    def _grad_sink(self, t, written):
+        """Where a consumer writes d/dt: the tensor's gradient buffer for the first writer of this
+        backward pass, a temporary that is added afterwards for later ones (passthrough fan-out)."""
+        gb, ld = self.gact[t]
+        if t not in written:
+            written.add(t)
+            return gb, ld, None
+        tmp = self.tmp_grad.get(t)
+        if tmp is None:
+            tmp = self.tmp_grad[t] = torch.zeros(self.B * t.h * t.w * ld, dtype=self.dtype, device=self.device)
+        n = self.B * t.h * t.w * ld
+        return tmp, ld, (lambda: ops.add_inplace(gb, tmp, n))
+
+    def backward(self, on_layer_done=None):
+        """Reverse sweep from the gradient already stored for the graph output (written by loss())."""
+        B = self.B
+        written = set()
+        inputs = set(self.graph.inputs.values())
+        for op in reversed(self.graph.ops):
+            kind = op['kind']
+            if kind == 'conv':
+                x, out = op['x'], op['out']
+                st = self.conv[op['name']]
+                M = B * out.h * out.w
+                cout, k = op['cout'], op['ksize']
+                ldy = pad8(cout)
+                gob, ldgo = self.gact[out]
+                xb, ldx = self.act[x]
+                if op['bn']:
+                    yb, _ = self.act[op['y']]
+                    gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
+                    ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
+                                            self.gvar[op['beta'].name], self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
+                    dy = self.dy_scratch
+                    ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
+                                           self.gvar[op['beta'].name], dy, M, cout, BN_EPS, LEAKY_ALPHA)
+                else:
+                    dy = gob
+                    assert ldgo == ldy
+                    ops.bias_grad(dy, ldy, self.gvar[op['biases'].name], self.ws, M, cout)
+                ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
+                if x not in inputs:
+                    dst, ldd, fin = self._grad_sink(x, written)
+                    self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
+                    if fin:
+                        fin()
+                if on_layer_done is not None:
+                    on_layer_done(op)
+            elif kind == 'pool':
+                x, out = op['x'], op['out']
+                dst, ldd, fin = self._grad_sink(x, written)
+                assert ldd == x.c
+                ops.maxpool_bwd(self.act[x][0], self.gact[out][0], dst, B, x.h, x.w, x.c, op['stride'])
+                if fin:
+                    fin()
+            elif kind == 'reorg':
+                x, out = op['x'], op['out']
+                dst, ldd, fin = self._grad_sink(x, written)
+                assert ldd == x.c
+                ops.reorg_bwd(self.gact[out][0], self.gact[out][1], dst, B, x.h, x.w, x.c)
+                if fin:
+                    fin()
+            elif kind == 'concat':
+                for v in op['inputs']:
+                    written.add(v)           # their gradients are slices of the concat gradient
+
+    def output(self):
+        return self.graph.ops[-1]['out']

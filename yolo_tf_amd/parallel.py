@@ -1,0 +1,92 @@
+"""Data parallelism over one 8xMI355X node: one process per GPU, full replica per GPU, gradients
+summed with RCCL (torch.distributed backend "nccl") over xGMI.  New work relative to the reference,
+which has no collective at all (README.md:99 "Multi-GPU supporting" unchecked).
+
+The flat gradient arena is laid out in reverse creation order, so as backward proceeds the finished
+region grows from offset 0.  ``GradReducer`` cuts it into buckets sized for xGMI (point-to-point
+links, ~153 GB/s each: a few large messages beat many small ones) and launches each bucket's
+all-reduce on a dedicated communication stream as soon as backward has passed it, so the
+collective overlaps the remaining backward kernels; the optimizer waits for the last bucket.  The
+1/world averaging is folded into the optimizer kernel (``gscale``).  Batch-norm statistics stay
+local to each replica."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def make_buckets(offsets_sizes, total, bucket_elems):
+    """Splits [0, total) at variable boundaries into contiguous buckets of >= bucket_elems elements
+    (the last one takes the remainder).  ``offsets_sizes``: iterable of (offset, size), any order."""
+    bounds = sorted(o + ((n + 3) // 4 * 4) for o, n in offsets_sizes)
+    buckets, start = [], 0
+    for b in bounds:
+        if b - start >= bucket_elems:
+            buckets.append((start, b))
+            start = b
+    if start < total:
+        buckets.append((start, total))
+    return buckets
+
+
+class GradReducer(object):
+    def __init__(self, grads, offsets_sizes, bucket_mb=64.0, group=None):
+        self.grads = grads
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = make_buckets(offsets_sizes, grads.numel(), int(bucket_mb * 1024 * 1024 / 4))
+        self.use_stream = grads.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.use_stream else None
+        self.next_bucket = 0
+        self.handles = []
+
+    def begin(self):
+        self.next_bucket = 0
+        self.handles = []
+
+    def ready_upto(self, end_offset):
+        """Backward has finished every gradient in [0, end_offset): launch the complete buckets."""
+        if self.world == 1:
+            return
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= end_offset:
+            s, e = self.buckets[self.next_bucket]
+            self._launch(self.grads[s:e])
+            self.next_bucket += 1
+
+    def _launch(self, view):
+        if self.use_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Flushes the remaining buckets and makes the compute stream wait for the collectives."""
+        if self.world == 1:
+            return
+        self.ready_upto(self.grads.numel())
+        if self.use_stream:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        else:
+            for h in self.handles:
+                h.wait()

@@ -1,0 +1,149 @@
+"""Training / detection sessions: the counterpart of what the reference's callers drive through
+``slim.learning.train`` (train.py:109-145) and ``sess.run`` (detect.py:69-71)."""
+import numpy as np
+import torch
+
+from . import ops
+from .engine import Engine
+from .graph import pad8
+from .model.yolo2 import OBJECTIVE_KEYS
+from .optim import Optimizer, learning_rate_fn
+from .parallel import GradReducer
+
+
+def _label_shapes(B, cells, C):
+    return [(B, cells), (B, cells, C), (B, cells, 4), (B, cells, 2), (B, cells, 2), (B, cells)]
+
+
+class TrainSession(object):
+    """One training replica.  ``step`` = per-image standardisation -> forward (batch-stat BN, EMA
+    update first: [TF-sem] UPDATE_OPS) -> loss + its gradient -> backward -> (all-reduce) -> optional
+    per-tensor clip -> optimizer; all asynchronous on the current stream."""
+
+    def __init__(self, builder, batch_size, dtype='bf16', optimizer='adam', learning_rate=1e-6, gradient_clip=0.0,
+                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0):
+        assert builder.training, 'call builder(data, training=True) first'
+        self.builder = builder
+        self.model = builder.model
+        self.engine = Engine(builder.graph, batch_size, dtype, training=True, seed=seed)
+        e = self.engine
+        self.B = batch_size
+        m = self.model
+        self.A, self.C = len(m.anchors), m.classes
+        dev = e.device
+        self.anchors = torch.from_numpy(m.anchors.reshape(-1)).to(dev)
+        self.labels = [torch.zeros(*s, dtype=torch.float32, device=dev) for s in _label_shapes(batch_size, m.cells, self.C)]
+        self.objectives_dev = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.loss_ws = torch.zeros(ops.loss_ws_floats(batch_size, m.cells, self.A), dtype=torch.float32, device=dev)
+        self.hparam = [builder.hparam[k] for k in OBJECTIVE_KEYS]
+        self.optimizer = Optimizer(optimizer, config if config is not None else builder.config, e.n_params, dev)
+        self.lr_fn = learning_rate_fn(config if config is not None else builder.config, learning_rate)
+        self.gradient_clip = float(gradient_clip)
+        self.clip_ws = torch.zeros(e.n_seg, dtype=torch.float64, device=dev)
+        self.global_step = 0
+        self.world_size = world_size
+        self.preprocess_mode = preprocess_mode
+        self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb) if world_size > 1 else None
+        # end offset (in the flat arena) of everything a conv layer owns: reverse creation order means
+        # offsets below it are complete once that layer's backward has run
+        self._layer_end = {}
+        for op in e.graph.ops:
+            if op['kind'] == 'conv':
+                names = [op['weights'].name] + [op[k].name for k in ('gamma', 'beta', 'biases') if k in op]
+                self._layer_end[op['name']] = max(e.param_offsets[n][0] + (e.param_offsets[n][1] + 3) // 4 * 4 for n in names)
+
+    def upload_labels(self, labels):
+        for dst, src in zip(self.labels, labels):
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(src, np.float32).reshape(dst.shape)), non_blocking=True)
+
+    def forward_backward(self, images):
+        e, m = self.engine, self.model
+        e.grads.zero_()
+        e.set_images(images, self.preprocess_mode)
+        e.forward()
+        out = e.output()
+        logits, ld = e.act[out]
+        dlogits, _ = e.gact[out]
+        ops.loss(logits, ld, self.anchors, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws,
+                 self.B, m.cell_height, m.cell_width, self.A, self.C)
+        if self.reducer is not None:
+            self.reducer.begin()
+            e.backward(on_layer_done=lambda op: self.reducer.ready_upto(self._layer_end[op['name']]))
+            self.reducer.finish()
+        else:
+            e.backward()
+
+    def apply_gradients(self):
+        e = self.engine
+        if self.gradient_clip > 0:
+            # [TF-sem] clip happens on the (averaged) gradient: scale first when data-parallel
+            if self.world_size > 1:
+                e.grads.mul_(1.0 / self.world_size)
+            ops.clip_by_norm(e.grads, e.seg_off, e.n_seg, self.gradient_clip, self.clip_ws)
+            gscale = 1.0
+        else:
+            gscale = 1.0 / self.world_size
+        lr = self.lr_fn(self.global_step)
+        self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale)
+        self.global_step += 1
+        e._filters_dirty = True
+
+    def step(self, images, labels=None):
+        if labels is not None:
+            self.upload_labels(labels)
+        self.forward_backward(images)
+        self.apply_gradients()
+
+    def fetch(self):
+        """Synchronises and returns {'total_loss', 'iou_best', 'iou_normal', 'coords', 'prob'} of the last step
+        (the five scalars the reference summarises, config.ini:63)."""
+        vals = self.objectives_dev.cpu().numpy().astype(np.float64)
+        out = {k: float(v) for k, v in zip(OBJECTIVE_KEYS, vals)}
+        out['total_loss'] = float(sum(v * w for v, w in zip(vals, self.hparam)))
+        self.builder.objectives.update({k: out[k] for k in OBJECTIVE_KEYS})
+        return out
+
+
+class DetectSession(object):
+    """Forward with moving-average BN + decode + batched on-GPU NMS (detect.py:69-80)."""
+
+    def __init__(self, builder, batch_size=1, dtype='bf16', seed=0):
+        assert not builder.training
+        self.builder = builder
+        self.model = m = builder.model
+        self.engine = Engine(builder.graph, batch_size, dtype, training=False, seed=seed)
+        dev = self.engine.device
+        self.B, self.A, self.C = batch_size, len(m.anchors), m.classes
+        n = m.cells * self.A
+        self.N = n
+        self.anchors = torch.from_numpy(m.anchors.reshape(-1)).to(dev)
+        self.conf = torch.zeros(batch_size, n, self.C, dtype=torch.float32, device=dev)
+        self.xy_min = torch.zeros(batch_size, n, 2, dtype=torch.float32, device=dev)
+        self.xy_max = torch.zeros(batch_size, n, 2, dtype=torch.float32, device=dev)
+        self.order = torch.zeros(batch_size, n, dtype=torch.int32, device=dev)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.nms_ws = torch.zeros(batch_size * n * self.C, dtype=torch.int32, device=dev)
+
+    def run(self, images, preprocess_mode=0, check_numerics=True):
+        """images: device f32 [B,H,W,3].  Returns device tensors conf [B,N,C], xy_min, xy_max [B,N,2]
+        (cell units).  Raises FloatingPointError on NaN/Inf like tf.check_numerics (detect.py:70)."""
+        e, m = self.engine, self.model
+        e.set_images(images, preprocess_mode)
+        e.forward()
+        logits, ld = e.act[e.output()]
+        self.nan_flag.zero_()
+        ops.head_decode(logits, ld, self.anchors, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height,
+                        m.cell_width, self.A, self.C)
+        if check_numerics and int(self.nan_flag.item()) != 0:
+            raise FloatingPointError('conf/xy_min/xy_max : Tensor had NaN or Inf values')
+        return self.conf, self.xy_min, self.xy_max
+
+    def nms(self, threshold=0.3, threshold_iou=0.4):
+        """In-place batched NMS on the decoded boxes; returns order [B,N] (reference list order)."""
+        ops.nms(self.conf, self.xy_min, self.xy_max, self.order, self.nms_ws, self.B, self.N, self.C, float(threshold), float(threshold_iou))
+        return self.order
+
+    def detect(self, images, threshold=0.3, threshold_iou=0.4, preprocess_mode=0):
+        self.run(images, preprocess_mode, check_numerics=False)
+        self.nms(threshold, threshold_iou)
+        return self.conf, self.xy_min, self.xy_max, self.order
