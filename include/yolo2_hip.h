@@ -50,6 +50,14 @@ int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O,
                  int B, int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize,
                  int dtype, void *stream);
 
+/* Same convolution with a caller-owned f32 workspace: when the M x N tile grid cannot fill the chip
+ * (13x13 / 26x26 stages at small batch) the K loop is sliced across workgroups, partial tiles are
+ * accumulated in `ws` (>= B*H*W*Nf floats for slicing to be considered; smaller = no slicing) and a
+ * finishing kernel writes O.  Results agree with yolo2_conv2d to f32 rounding of the partial sums. */
+int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws,
+                    size_t ws_bytes, int B, int H, int W, int Cp, int ldp, int Nf, int ldo,
+                    int ksize, int dtype, void *stream);
+
 /* Filter gradient of the same convolution (tf.gradients of conv2d, train.py:127-129):
  *   dW[r,s,c,n] += sum_{b,h,w} X[b,h+r-pad,w+s-pad,c] * dY[b,h,w,n]       (HWIO, f32)
  * dW must be zeroed by the caller: pixel-range splits accumulate with f32 atomics. */
@@ -66,7 +74,8 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
 
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
-/* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 2*C doubles (any content) */
+/* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1024*C doubles of scratch
+ * (per-block partial sums; any content) */
 int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C,
                    int dtype, void *stream);
 /* moving -= f32(1-decay)*(moving-batch)   (assign_moving_average, decay 0.999; 1-decay is formed in
@@ -78,7 +87,7 @@ int yolo2_bn_leaky(const void *Y, const float *mean, const float *var, const flo
                    const float *beta, void *A, long M, int C, int lda, float eps, float alpha,
                    int dtype, void *stream);
 /* backward, pass 1: dgamma[c] = sum g*xhat, dbeta[c] = sum g with g = dA * leaky'(z);
- * ws: >= 2*C doubles */
+ * ws: >= 1024*C doubles of scratch */
 int yolo2_bn_leaky_bwd_reduce(const void *dA, int ldda, const void *Y, const float *mean,
                               const float *var, const float *gamma, const float *beta,
                               float *dgamma, float *dbeta, double *ws, long M, int C,
@@ -109,7 +118,7 @@ int yolo2_copy_channels(const void *src, int lds, void *dst, int ldd, long M, in
                         void *stream);
 /* dst += src elementwise over n elements (passthrough gradient join) */
 int yolo2_add_inplace(void *dst, const void *src, long n, int dtype, void *stream);
-/* dbias[c] = sum_m dY[m,c]  (final conv biases, model/yolo2/inference.py:118); ws >= C doubles */
+/* dbias[c] = sum_m dY[m,c]  (final conv biases, model/yolo2/inference.py:118); ws >= 512*ld doubles */
 int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, int C, int dtype,
                     void *stream);
 

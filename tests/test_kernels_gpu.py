@@ -187,7 +187,7 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
 
     yd, dad = dev(y, tdtype), dev(da, tdtype)
     mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    ws = torch.zeros(2 * C, dtype=torch.float64, device='cuda')
+    ws = torch.zeros(1024 * C, dtype=torch.float64, device='cuda')
     ops.bn_stats(yd, mean, var, ws, M, C)
     lda = C + 16
     A = torch.zeros(M * lda, dtype=tdtype, device='cuda')
@@ -271,7 +271,7 @@ def test_copy_add_biasgrad(ops):
     dy = np.zeros((M, ld), np.float32)
     dy[:, :C] = rng.randn(M, C)
     db = torch.zeros(C, device='cuda')
-    ws = torch.zeros(2 * ld, dtype=torch.float64, device='cuda')
+    ws = torch.zeros(512 * ld, dtype=torch.float64, device='cuda')
     ops.bias_grad(dev(dy), ld, db, ws, M, C)
     dst = torch.zeros(M * 256, device='cuda')
     ops.copy_channels(dev(dy), ld, dst, 256, M, 64)

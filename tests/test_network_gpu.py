@@ -47,12 +47,15 @@ def basedir():
         yield d
 
 
-@pytest.mark.parametrize('inference,size,dtype', [('darknet', 64, 'f32'), ('tiny', 64, 'f32'), ('darknet', 96, 'f32'),
-                                                  ('darknet', 64, 'bf16'), ('tiny', 64, 'bf16')])
-def test_train_step_matches_oracle(basedir, inference, size, dtype):
+# Sizes: the 13x13-stage layers see B*(size/32)^2 samples per channel in their batch statistics; below
+# ~16 samples batch norm is ill-conditioned (a near-zero batch variance amplifies rounding), so the
+# f32 cases use 96/128 px and the bf16 cases 160 px with batch 4 (100 samples).
+@pytest.mark.parametrize('inference,size,dtype,B', [('darknet', 96, 'f32', 2), ('tiny', 96, 'f32', 2), ('darknet', 128, 'f32', 3),
+                                                    ('darknet', 160, 'bf16', 4), ('tiny', 160, 'bf16', 4)])
+def test_train_step_matches_oracle(basedir, inference, size, dtype, B):
     from yolo_tf_amd.session import TrainSession
     from yolo_tf_amd.utils import data
-    B, classes = 2, 20
+    classes = 20
     b, cfg = make_builder(inference, classes, size, True, basedir)
     sess = TrainSession(b, B, dtype=dtype, optimizer='adam', learning_rate=1e-3, seed=3)
     scope = 'yolo2_' + inference
@@ -86,8 +89,9 @@ def test_train_step_matches_oracle(basedir, inference, size, dtype):
     for k in R.OBJECTIVE_KEYS:
         assert abs(got[k] - info['objectives'][k]) <= tol_loss * abs(info['objectives'][k]) + 1e-7, (k, got[k], info['objectives'][k])
     assert abs(got['total_loss'] - info['loss']) <= tol_loss * abs(info['loss'])
-    worst = max((rel(grads[k], info['grads'][k]), k) for k in grads)
-    assert worst[0] <= tol_grad, 'worst gradient rel err %.3e at %s' % worst
+    errs = sorted(((rel(grads[k], info['grads'][k]), k) for k in grads), reverse=True)
+    print('logits rel %.2e; worst gradient rel errs: %s' % (r, ['%s %.2e' % (k, v) for v, k in errs[:4]]))
+    assert errs[0][0] <= tol_grad, 'worst gradient rel err %.3e at %s' % errs[0]
     if f32:
         # Adam moves every weight by ~lr at step 1 regardless of gradient magnitude, so compare the update direction
         for k in ('conv0/weights', 'conv/weights', 'conv/biases'):
@@ -111,7 +115,7 @@ def test_detect_matches_oracle(basedir):
         if k.endswith('moving_mean'):
             params[k] = (rng.randn(*params[k].shape) * 0.05).astype(np.float32)
         if k.endswith('moving_variance'):
-            params[k] = (rng.rand(*params[k].shape) * 0.5 + 0.05).astype(np.float32)
+            params[k] = (rng.rand(*params[k].shape) + 0.5).astype(np.float32)
     params['conv/biases'] = (rng.randn(*params['conv/biases'].shape)).astype(np.float32)
     sess.engine.set_variables({scope + '/' + k: v for k, v in params.items()})
     images = rng.uniform(0, 255, (B, size, size, 3)).astype(np.float32)

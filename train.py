@@ -1,0 +1,149 @@
+#!/usr/bin/env python
+"""train.py -- YOLO/YOLOv2 training on MI355X with the reference CLI (ruiminshen/yolo-tf train.py:148-167):
+
+    python train.py -c config.ini config/yolo2/darknet-20.ini -b 16 -o adam -lr 1e-4 -s 1000
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py -c ... -b 8
+
+Same flags (-c -t -e -p -s -d -b -o -n -g -lr --seed --summary_secs --save_secs --level --master
+--task); same logdir/cachedir layout, auto-resume from the latest checkpoint in logdir, `-d` wipes
+it, `-t/-e` transfers variables.  One process per GPU; `-b` is the per-GPU batch.  The reference's
+TFRecord/JPEG input pipeline is out of the hot-path scope: batches come from
+``--data synthetic`` (seeded generator, default) or ``--data file.npz`` (images uint8 [N,H,W,3],
+labels produced by utils.data.transform_labels)."""
+import argparse
+import configparser
+import logging
+import os
+import shutil
+import time
+
+import numpy as np
+import torch
+
+from yolo_tf_amd import checkpoint, utils
+from yolo_tf_amd.parallel import init_distributed
+from yolo_tf_amd.session import TrainSession
+from yolo_tf_amd.utils import data as udata
+
+
+def make_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-c', '--config', nargs='+', default=['config.ini'], help='config file')
+    parser.add_argument('-t', '--transfer', help='transferring model from a checkpoint file')
+    parser.add_argument('-e', '--exclude', nargs='+', help='exclude variables while transferring')
+    parser.add_argument('-p', '--profile', nargs='+', default=['train', 'val'])
+    parser.add_argument('-s', '--steps', type=int, default=None, help='max number of steps')
+    parser.add_argument('-d', '--delete', action='store_true', help='delete logdir')
+    parser.add_argument('-b', '--batch_size', default=8, type=int, help='batch size (per GPU)')
+    parser.add_argument('-o', '--optimizer', default='adam')
+    parser.add_argument('-n', '--logname', default=time.strftime('%Y-%m-%d_%H-%M-%S'), help='run name')
+    parser.add_argument('-g', '--gradient_clip', default=0, type=float, help='gradient clip')
+    parser.add_argument('-lr', '--learning_rate', default=1e-6, type=float, help='learning rate')
+    parser.add_argument('--seed', type=int, default=None)
+    parser.add_argument('--summary_secs', default=30, type=int, help='seconds between logged summaries')
+    parser.add_argument('--save_secs', default=600, type=int, help='seconds to save model')
+    parser.add_argument('--level', help='logging level')
+    parser.add_argument('--master', default='', help='accepted for compatibility (rendezvous comes from torch.distributed.run)')
+    parser.add_argument('--task', type=int, default=0, help='accepted for compatibility (rank comes from RANK)')
+    parser.add_argument('--data', default='synthetic', help="'synthetic' or a .npz file")
+    parser.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='overrides [mi355x] dtype')
+    return parser.parse_args()
+
+
+class SyntheticData(object):
+    def __init__(self, batch, classes, width, height, cell_width, cell_height, seed):
+        self.args = (batch, classes, cell_width, cell_height)
+        self.gen = torch.Generator(device='cuda').manual_seed(seed)
+        self.shape = (batch, height, width, 3)
+        self.seed = seed
+        self.i = 0
+
+    def next(self):
+        images = torch.rand(*self.shape, device='cuda', generator=self.gen) * 255.0
+        labels = udata.synthetic_batch(*self.args, seed=self.seed * 1000003 + self.i)
+        self.i += 1
+        return images, labels
+
+
+class NpzData(object):
+    def __init__(self, path, batch, seed, rank, world):
+        z = np.load(path)
+        self.images = z['images']
+        self.labels = [z[k] for k in udata.LABEL_KEYS]
+        self.batch = batch
+        self.rng = np.random.RandomState(seed)
+        self.rank, self.world = rank, world
+
+    def next(self):
+        idx = self.rng.randint(0, len(self.images), self.batch * self.world)[self.rank::self.world]
+        images = torch.from_numpy(self.images[idx].astype(np.float32)).cuda()
+        return images, tuple(l[idx] for l in self.labels)
+
+
+def main():
+    rank, local_rank, world = init_distributed()
+    torch.cuda.set_device(local_rank)
+    model = config.get('config', 'model')
+    logdir = utils.get_logdir(config)
+    if args.delete and rank == 0:
+        logging.warning('delete logging directory: ' + logdir)
+        shutil.rmtree(logdir, ignore_errors=True)
+    utils.ensure_names(config)
+    width = config.getint(model, 'width')
+    height = config.getint(model, 'height')
+    cell_width, cell_height = utils.calc_cell_width_height(config, width, height)
+    logging.warning('(width, height)=(%d, %d), (cell_width, cell_height)=(%d, %d)' % (width, height, cell_width, cell_height))
+    yolo = __import__('yolo_tf_amd.model.' + model, fromlist=['Builder'])
+    builder = yolo.Builder(args, config)
+    builder(None, training=True)
+    builder.create_objectives()
+    dtype = args.dtype or (config.get('mi355x', 'dtype') if config.has_option('mi355x', 'dtype') else 'bf16')
+    seed = args.seed if args.seed is not None else 0
+    session = TrainSession(builder, args.batch_size, dtype=dtype, optimizer=args.optimizer, learning_rate=args.learning_rate,
+                           gradient_clip=args.gradient_clip, config=config, seed=seed, world_size=world,
+                           bucket_mb=config.getfloat('mi355x', 'bucket_mb') if config.has_option('mi355x', 'bucket_mb') else 64.0)
+    logging.warning('optimizer=%s, dtype=%s, world=%d, parameters=%d' % (args.optimizer, dtype, world, session.engine.n_params))
+    latest = checkpoint.latest_checkpoint(logdir)
+    if latest:
+        step = checkpoint.restore(latest, session)
+        logging.warning('resuming from %s (global_step=%d)' % (latest, step))
+    elif args.transfer:
+        path = os.path.expanduser(os.path.expandvars(args.transfer))
+        logging.warning('transferring from ' + path)
+        checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+    logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
+    if args.data == 'synthetic':
+        data = SyntheticData(args.batch_size, len(builder.names), width, height, cell_width, cell_height, seed * world + rank + 1)
+    else:
+        data = NpzData(args.data, args.batch_size, seed, rank, world)
+    last_summary = last_save = t_rate = time.time()
+    n_rate = 0
+    while args.steps is None or session.global_step < args.steps:
+        images, labels = data.next()
+        session.step(images, labels)
+        n_rate += 1
+        now = time.time()
+        if now - last_summary >= args.summary_secs or (args.steps is not None and session.global_step >= args.steps):
+            s = session.fetch()
+            rate = n_rate * args.batch_size * world / (time.time() - t_rate)
+            if rank == 0:
+                logging.warning('step %d: total_loss=%.6f iou_best=%.6f iou_normal=%.6f coords=%.6f prob=%.6f (%.1f img/s)'
+                                % (session.global_step, s['total_loss'], s['iou_best'], s['iou_normal'], s['coords'], s['prob'], rate))
+            if not np.isfinite(s['total_loss']):
+                raise FloatingPointError('total_loss is not finite')
+            last_summary, t_rate, n_rate = now, time.time(), 0
+        if rank == 0 and now - last_save >= args.save_secs:
+            logging.warning('saved ' + checkpoint.save(logdir, session))
+            last_save = now
+    if rank == 0:
+        logging.warning('saved ' + checkpoint.save(logdir, session))
+
+
+if __name__ == '__main__':
+    args = make_args()
+    config = configparser.ConfigParser()
+    utils.load_config(config, args.config)
+    logging.basicConfig(format='%(asctime)s %(message)s')
+    if args.level:
+        logging.getLogger().setLevel(args.level.upper())
+    main()

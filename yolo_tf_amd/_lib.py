@@ -26,6 +26,7 @@ _f = ctypes.c_float
 # name -> argument ctypes (return type is always int unless noted)
 SIGNATURES = {
     'yolo2_conv2d': [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_conv2d_ws': [_p, _p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_conv2d_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],

@@ -18,6 +18,7 @@
 // blockIdx -> tile: filter tile fastest, so the blocks an XCD receives (bid % 8) keep re-using
 // the same filter slab from that XCD's private L2 while sweeping M.
 #include "common.h"
+#include <stdlib.h>
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -41,18 +42,21 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BN, int WGN>
+// CH = 16-byte chunks per LDS row (K step = CH*16 bytes of channels); SPLITK: gridDim.y slices of the
+// K loop accumulate f32 partial tiles into Oacc with hardware atomics (finished by splitk_finish_kernel)
+template <typename T, int BN, int WGN, int CH, bool SPLITK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T *__restrict__ P, const T *__restrict__ F, const float *__restrict__ bias,
-    T *__restrict__ O, int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, int M, int NT) {
+    T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, int M, int NT) {
     constexpr int BM = 128;
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int BK = 4 * VEC;
-    constexpr int LDS = BK + VEC;  // row stride in elements (80 bytes)
+    constexpr int BK = CH * VEC;
+    constexpr int LDS = BK + VEC;  // row stride: CH*16 + 16 bytes (80 / 144 B: conflict-free b128 fragment reads)
     constexpr int WGM = 4 / WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int A_IT = BM * 4 / 256;
-    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int RPP = 256 / CH;                 // rows covered per pass of the 256 threads
+    constexpr int A_IT = BM / RPP;
+    constexpr int B_IT = (BN + RPP - 1) / RPP;
     static_assert(TM >= 1 && TN >= 1, "tile");
 
     __shared__ __attribute__((aligned(16))) T smem[2][(BM + BN) * LDS];
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const int wm = wave / WGN, wn = wave % WGN;
     const int nt = blockIdx.x % NT, mt = blockIdx.x / NT;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int chunk = tid & 3;
+    const int chunk = tid % CH, trow = tid / CH;
     const int Ktot = ksize * ksize * Cp;
     const int pad = ksize >> 1;
 
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     long a_off[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        int m = m0 + (tid >> 2) + i * 64;
+        int m = m0 + trow + i * RPP;
         if (m < M) {
             int rem = m % (H * W);
             a_h[i] = rem / W;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     bool b_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        int row = (tid >> 2) + i * 64;
+        int row = trow + i * RPP;
         int n = n0 + row;
         b_ok[i] = (row < BN) && (n < Nf);
         b_off[i] = (long)n * Ktot;
@@ -123,22 +127,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         T *As = smem[buf];
         T *Bs = smem[buf] + BM * LDS;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) st16(As + ((tid >> 2) + i * 64) * LDS + chunk * VEC, ra[i]);
+        for (int i = 0; i < A_IT; ++i) st16(As + (trow + i * RPP) * LDS + chunk * VEC, ra[i]);
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
-            int row = (tid >> 2) + i * 64;
+            int row = trow + i * RPP;
             if (row < BN) st16(Bs + row * LDS + chunk * VEC, rb[i]);
         }
     };
 
-    int tap = 0, c0 = 0;
+    int kt_beg = 0, kt_end = nk;
+    if (SPLITK) {
+        const int per = (nk + gridDim.y - 1) / gridDim.y;
+        kt_beg = blockIdx.y * per;
+        kt_end = min(nk, kt_beg + per);
+        if (kt_beg >= kt_end) return;
+    }
+    int tap = kt_beg / kpt, c0 = (kt_beg - tap * kpt) * BK;
     g_load(tap, c0);
     s_store(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        const int cur = (kt - kt_beg) & 1;
+        const bool more = kt + 1 < kt_end;
         if (more) {
             c0 += BK;
             if (c0 >= Cp) { c0 = 0; ++tap; }
@@ -167,46 +178,113 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (n >= Nf) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const float bv = (!SPLITK && bias) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) O[(long)m * ldo + n] = (T)(acc[i][j][r] + bv);
+                if (m < M) {
+                    if (SPLITK) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
+                    else O[(long)m * ldo + n] = (T)(acc[i][j][r] + bv);
+                }
             }
         }
     }
 }
 
+// f32 partial sums [M][Nf] -> O (dtype, pixel stride ldo) + bias
 template <typename T>
-static int launch_conv(const void *P, const void *F, const float *bias, void *O, int B, int H, int W,
+__global__ void splitk_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, T *__restrict__ O, long M, int Nf, int ldo) {
+    const long total = M * Nf;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / Nf;
+        const int n = (int)(i - m * Nf);
+        O[m * ldo + n] = (T)(acc[i] + (bias ? bias[n] : 0.f));
+    }
+}
+
+// number of K slices: aim at >= 3 resident blocks per CU (register-limited occupancy of the 128-wide
+// tile) when the M x N tile grid alone cannot fill 256 CUs, keeping >= 8 K tiles per slice
+struct Tune { int ch; int target_blocks; };
+static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
+    static Tune t = [] {
+        Tune v{8, 512};
+        if (const char *e = getenv("YOLO2_IGEMM_CH")) v.ch = atoi(e) == 4 ? 4 : 8;
+        if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
+        return v;
+    }();
+    return t;
+}
+static int choose_ksplit(int tiles, int nk, int target) {
+    if (target <= 0 || tiles * 3 >= target * 2 || nk < 32) return 1;
+    int ks = (target + tiles - 1) / tiles;
+    int max_ks = nk / 8;
+    if (ks > max_ks) ks = max_ks;
+    return ks < 1 ? 1 : ks;
+}
+
+template <typename T>
+static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
                        int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
+    constexpr int VEC = 16 / sizeof(T);
     if (Nf > 64) {
         const int NT = cdiv(Nf, 128);
-        conv_igemm_kernel<T, 128, 2><<<MT * NT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+        const Tune &tu = tune();
+        const int CHsel = (Cp >= 8 * VEC) ? tu.ch : 4;
+        const int nk = ksize * ksize * cdiv(Cp, CHsel * VEC);
+        int ks = ws ? choose_ksplit(MT * NT, nk, tu.target_blocks) : 1;
+        if (ks > 1 && (size_t)M * Nf * sizeof(float) > ws_bytes) ks = 1;
+        if (ks > 1) {
+            if (hipMemsetAsync(ws, 0, (size_t)M * Nf * sizeof(float), st) != hipSuccess) return 1;
+            dim3 grid(MT * NT, ks);
+            if (CHsel == 8)
+                conv_igemm_kernel<T, 128, 2, 8, true><<<grid, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+            else
+                conv_igemm_kernel<T, 128, 2, 4, true><<<grid, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+            long total = (long)M * Nf;
+            int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo);
+        } else if (CHsel == 8) {
+            conv_igemm_kernel<T, 128, 2, 8, false><<<MT * NT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+        } else {
+            conv_igemm_kernel<T, 128, 2, 4, false><<<MT * NT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+        }
     } else if (Nf > 32) {
-        conv_igemm_kernel<T, 64, 1><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
+        conv_igemm_kernel<T, 64, 1, 4, false><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
     } else {
-        conv_igemm_kernel<T, 32, 1><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
+        conv_igemm_kernel<T, 32, 1, 4, false><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
     }
     return 0;
 }
 
-extern "C" int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O, int B, int H,
-                            int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream) {
-    Y2_CHECK_ARG(P && F && O);
-    Y2_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0);
-    Y2_CHECK_ARG(ksize == 1 || ksize == 3);
-    Y2_CHECK_ARG(ldp >= Cp && ldo >= Nf);
-    Y2_CHECK_ARG((long)B * H * W * (long)(ldp > ldo ? ldp : ldo) < (1L << 31));
+static int conv2d_impl(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H,
+                       int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn) {
+    if (!(P && F && O) || !(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0) || !(ksize == 1 || ksize == 3) || !(ldp >= Cp && ldo >= Nf)) {
+        yolo2_set_error("%s: argument check failed: pointers / extents / ksize / strides", fn);
+        return YOLO2_E_ARG;
+    }
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
-    Y2_CHECK_ARG(Cp % vec == 0 && ldp % vec == 0);
-    Y2_CHECK_ARG(((uintptr_t)P & 15) == 0 && ((uintptr_t)F & 15) == 0);
-    Y2_DISPATCH_DTYPE(dtype, launch_conv<T>(P, F, bias, O, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream));
+    if ((long)B * H * W * (long)(ldp > ldo ? ldp : ldo) >= (1L << 31) || Cp % vec || ldp % vec || ((uintptr_t)P & 15) || ((uintptr_t)F & 15)) {
+        yolo2_set_error("%s: argument check failed: size / alignment (channels must be a multiple of %d)", fn, vec);
+        return YOLO2_E_ARG;
+    }
+    int rc = 0;
+    Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream));
+    if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
+}
+
+extern "C" int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O, int B, int H,
+                            int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream) {
+    return conv2d_impl(P, F, bias, O, nullptr, 0, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d");
+}
+
+extern "C" int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B,
+                               int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream) {
+    return conv2d_impl(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_ws");
 }

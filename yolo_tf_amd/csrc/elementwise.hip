@@ -90,73 +90,95 @@ struct RowMap {  // fixed channel group per thread, rows strided
     }
 };
 
-// reduce V per-thread partial vectors (N values each) across the row slots of a block and add
-// the per-channel totals to double accumulators out[k*C + c]
+// Column reductions are two-stage and atomic-free: every block reduces its row slots through LDS
+// and stores one f32 partial per (quantity, channel) at part[(k*nb + block)*C + c]; a second kernel
+// sums the nb partials per channel in f64 and applies the finalisation (mean/var, dgamma/dbeta,
+// bias gradient).  (A first version used f64 atomics on 2*C addresses: 2048 blocks contending on
+// 64 addresses made the reductions 40 % of the training step.)
 template <int N, int K>
-__device__ __forceinline__ void block_colsum_commit(const float (&part)[K][N], const RowMap &rm, int C, double *out) {
-    __shared__ float red[K][256 * 8 / 8][N];  // [K][256][N] floats: N<=8, K<=2 -> 16 KB
-    if (threadIdx.x < 256) {
+__device__ __forceinline__ void block_colsum_store(const float (&part)[K][N], const RowMap &rm, int C, float *out, int nb) {
+    __shared__ float red[K][256][N];  // N<=8, K<=2 -> 16 KB
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+    for (int k = 0; k < K; ++k)
 #pragma unroll
-            for (int j = 0; j < N; ++j) red[k][threadIdx.x][j] = rm.active ? part[k][j] : 0.f;
-    }
+        for (int j = 0; j < N; ++j) red[k][threadIdx.x][j] = rm.active ? part[k][j] : 0.f;
     __syncthreads();
     if (threadIdx.x < rm.tpr) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                double s = 0.0;
-                for (int r = 0; r < rm.rpp; ++r) s += (double)red[k][r * rm.tpr + threadIdx.x][j];
-                atomicAdd(out + (long)k * C + threadIdx.x * N + j, s);
+                float s = 0.f;
+                for (int r = 0; r < rm.rpp; ++r) s += red[k][r * rm.tpr + threadIdx.x][j];
+                out[((long)k * nb + blockIdx.x) * C + threadIdx.x * N + j] = s;
             }
     }
 }
 
-// MODE 0: sum x ; MODE 1: sum (x - mean)^2 with mean = ws_sum/M
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, const double *__restrict__ sum_in, double *__restrict__ out) {
+// K = 2: sum x and sum x^2 (single pass; the f64 finalisation forms E[x^2] - mean^2);  K = 1: sum x
+template <typename T, int K>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, float *__restrict__ part) {
     constexpr int N = Vec16<T>::N;
     RowMap rm(C, N);
-    float part[1][N];
-    float mean[N];
+    float acc[K][N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        part[0][j] = 0.f;
-        mean[j] = (MODE == 1 && rm.active) ? (float)(sum_in[rm.cg * N + j] / (double)M) : 0.f;
-    }
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[k][j] = 0.f;
     if (rm.active) {
         for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
             Vec16<T> v = ld16(X + r * ld + rm.cg * N);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float x = v.get(j);
-                if (MODE == 0) part[0][j] += x;
-                else { float d = x - mean[j]; part[0][j] += d * d; }
+                acc[0][j] += x;
+                if (K == 2) acc[K - 1][j] += x * x;
             }
         }
     }
-    block_colsum_commit<N, 1>(part, rm, C, out);
+    block_colsum_store<N, K>(acc, rm, C, part, gridDim.x);
 }
 
-__global__ void bn_finalize_kernel(const double *__restrict__ ws, float *__restrict__ mean, float *__restrict__ var, long M, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        mean[c] = (float)(ws[c] / (double)M);
-        var[c] = (float)(ws[C + c] / (double)M);
+// FIN 0: (sum x, sum x^2) -> mean, biased var;  FIN 1: two sums -> two f32 outputs;  FIN 2: one sum -> o0
+template <int FIN>
+__global__ __launch_bounds__(256) void reduce_finalize_kernel(const float *__restrict__ part, int nb, int C, long M,
+                                                              float *__restrict__ o0, float *__restrict__ o1, int nout) {
+    constexpr int K = FIN == 2 ? 1 : 2;
+    __shared__ double red[K][4][64];
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + col;
+    double s[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        s[k] = 0.0;
+        if (c < C)
+            for (int b = rg; b < nb; b += 4) s[k] += (double)part[((long)k * nb + b) * C + c];
+        red[k][rg][col] = s[k];
     }
-}
-__global__ void colsum_finalize_kernel(const double *__restrict__ ws, float *__restrict__ out, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) out[c] = (float)ws[c];
+    __syncthreads();
+    if (rg == 0 && c < nout) {
+        double t[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) t[k] = red[k][0][col] + red[k][1][col] + red[k][2][col] + red[k][3][col];
+        if (FIN == 0) {
+            double mean = t[0] / (double)M;
+            double var = t[K - 1] / (double)M - mean * mean;
+            o0[c] = (float)mean;
+            o1[c] = (float)(var > 0.0 ? var : 0.0);
+        } else if (FIN == 1) {
+            o0[c] = (float)t[0];
+            o1[c] = (float)t[K - 1];
+        } else {
+            o0[c] = (float)t[0];
+        }
+    }
 }
 
 static int colsum_grid(long M, int C, int vec) {
     int tpr = C / vec, rpp = 256 / tpr;
     if (rpp < 1) rpp = 1;
-    long g = (M + (long)rpp * 8 - 1) / ((long)rpp * 8);
-    if (g > 2048) g = 2048;
+    long g = (M + (long)rpp * 4 - 1) / ((long)rpp * 4);
+    if (g > 1024) g = 1024;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -166,11 +188,10 @@ extern "C" int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { yolo2_set_error("bn_stats: memset failed"); return YOLO2_E_LAUNCH; }
-    int grid = colsum_grid(M, C, vec);
-    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 0><<<grid, 256, 0, st>>>((const T *)Y, C, M, C, nullptr, ws));
-    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 1><<<grid, 256, 0, st>>>((const T *)Y, C, M, C, ws, ws + C));
-    bn_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, mean, var, M, C);
+    const int nb = colsum_grid(M, C, vec);
+    float *part = (float *)ws;
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 2><<<nb, 256, 0, st>>>((const T *)Y, C, M, C, part));
+    reduce_finalize_kernel<0><<<cdiv(C, 64), 256, 0, st>>>(part, nb, C, M, mean, var, C);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -181,10 +202,10 @@ extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws,
     Y2_CHECK_ARG(ld % vec == 0 && ld / vec <= 256);
     hipStream_t st = (hipStream_t)stream;
     // reduce over the padded width ld (padding lanes are zero by contract), report the first C
-    if (hipMemsetAsync(ws, 0, sizeof(double) * ld, st) != hipSuccess) { yolo2_set_error("bias_grad: memset failed"); return YOLO2_E_LAUNCH; }
-    int grid = colsum_grid(M, ld, vec);
-    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 0><<<grid, 256, 0, st>>>((const T *)dY, ld, M, ld, nullptr, ws));
-    colsum_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, dbias, C);
+    const int nb = colsum_grid(M, ld, vec);
+    float *part = (float *)ws;
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 1><<<nb, 256, 0, st>>>((const T *)dY, ld, M, ld, part));
+    reduce_finalize_kernel<2><<<cdiv(ld, 64), 256, 0, st>>>(part, nb, ld, M, dbias, nullptr, C);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -255,7 +276,7 @@ extern "C" int yolo2_bn_leaky(const void *Y, const float *mean, const float *var
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict__ dA, int ldda, const T *__restrict__ Y, const float *__restrict__ mean,
                                                             const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            double *__restrict__ ws, long M, int C, float eps, float alpha) {
+                                                            float *__restrict__ ws, long M, int C, float eps, float alpha) {
     constexpr int N = Vec16<T>::N;
     RowMap rm(C, N);
     float part[2][N];
@@ -283,13 +304,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
             }
         }
     }
-    block_colsum_commit<N, 2>(part, rm, C, ws);
+    block_colsum_store<N, 2>(part, rm, C, ws, gridDim.x);
 }
-__global__ void bn_bwd_finalize_kernel(const double *__restrict__ ws, float *dgamma, float *dbeta, int C) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) { dgamma[c] = (float)ws[c]; dbeta[c] = (float)ws[C + c]; }
-}
-
 extern "C" int yolo2_bn_leaky_bwd_reduce(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
                                          const float *beta, float *dgamma, float *dbeta, double *ws, long M, int C, float eps, float alpha,
                                          int dtype, void *stream) {
@@ -297,10 +313,10 @@ extern "C" int yolo2_bn_leaky_bwd_reduce(const void *dA, int ldda, const void *Y
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, st) != hipSuccess) { yolo2_set_error("bn_bwd_reduce: memset failed"); return YOLO2_E_LAUNCH; }
-    int grid = colsum_grid(M, C, vec);
-    Y2_DISPATCH_DTYPE(dtype, bn_bwd_reduce_kernel<T><<<grid, 256, 0, st>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, ws, M, C, eps, alpha));
-    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, st>>>(ws, dgamma, dbeta, C);
+    const int nb = colsum_grid(M, C, vec);
+    float *part = (float *)ws;
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_reduce_kernel<T><<<nb, 256, 0, st>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, part, M, C, eps, alpha));
+    reduce_finalize_kernel<1><<<cdiv(C, 64), 256, 0, st>>>(part, nb, C, M, dgamma, dbeta, C);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

@@ -134,7 +134,10 @@ class Engine(object):
             self.conv[op['name']] = st
             max_y = max(max_y, B * op['out'].h * op['out'].w * ldy)
             max_c = max(max_c, ldy)
-        self.ws = torch.zeros(2 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)
+        # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
+        # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
+        self.conv_ws = torch.zeros(min(max(max_y, 1), 8 * 1024 * 1024), dtype=torch.float32, device=dev)
+        self.ws = torch.zeros(1024 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
             self.dy_scratch = torch.zeros(max_y, dtype=T, device=dev)
             self.tmp_grad = {}
@@ -148,7 +151,7 @@ class Engine(object):
         t = self.kernel_timer if Nf > 64 else None
         if t is not None:
             t.start(2.0 * self.B * H * W * Nf * real_k)
-        ops.conv2d(P, F, bias, O, self.B, H, W, Cp, ldp, Nf, ldo, k)
+        ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
         if t is not None:
             t.stop()
 

@@ -20,6 +20,11 @@ def conv2d(P, F, bias, O, B, H, W, Cp, ldp, Nf, ldo, ksize):
     call('yolo2_conv2d', ptr(P), ptr(F), ptr(bias), ptr(O), B, H, W, Cp, ldp, Nf, ldo, ksize, dtype_code(P.dtype), _stream())
 
 
+def conv2d_ws(P, F, bias, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize):
+    call('yolo2_conv2d_ws', ptr(P), ptr(F), ptr(bias), ptr(O), ptr(ws), ws.numel() * ws.element_size(), B, H, W, Cp, ldp, Nf, ldo, ksize,
+         dtype_code(P.dtype), _stream())
+
+
 def conv2d_wgrad(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize):
     call('yolo2_conv2d_wgrad', ptr(X), ptr(dY), ptr(dW), B, H, W, Cin, ldx, Cout, ldy, ksize, dtype_code(X.dtype), _stream())
 
