@@ -74,7 +74,7 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
 
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
-/* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1024*C doubles of scratch
+/* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1025*C doubles of scratch
  * (per-block partial sums; any content) */
 int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C,
                    int dtype, void *stream);

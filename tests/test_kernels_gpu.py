@@ -115,6 +115,31 @@ def test_conv_dgrad(ops, shape, mode):
     assert_close(got, ref, F32_RTOL if mode == 'f32' else BF16_RTOL, 'conv dgrad %s %s' % (shape, mode))
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 13, 13, 512, 256, 3), (1, 13, 13, 1024, 125, 1), (2, 26, 26, 256, 136, 3)])
+def test_conv_forward_ksliced(ops, shape, mode):
+    """yolo2_conv2d_ws: K loop sliced across workgroups (small M x N grids), f32 partial tiles + finishing kernel."""
+    B, H, W, Cin, Cout, k = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(sum(shape))
+    x = rng.randn(B, H, W, Cin).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
+    bias = rng.randn(Cout).astype(np.float32)
+    if mode == 'bf16':
+        x, w = bf16_round(x), bf16_round(w)
+    ref = R.conv2d(x, w) + bias
+    ldo = ops.pad8(Cout)
+    F = torch.zeros(Cout * k * k * Cin, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, ldo, tdtype)
+    O = torch.zeros(B * H * W * ldo, dtype=tdtype, device='cuda')
+    ws = torch.full((B * H * W * Cout + 64,), 5.0, dtype=torch.float32, device='cuda')    # dirty on purpose
+    ops.conv2d_ws(dev(x, tdtype), F, dev(bias), O, ws, B, H, W, Cin, Cin, Cout, ldo, k)
+    torch.cuda.synchronize()
+    y = host(O).reshape(B, H, W, ldo)
+    assert np.all(y[..., Cout:] == 0)
+    assert_close(y[..., :Cout], ref, F32_RTOL if mode == 'f32' else BF16_RTOL, 'conv fwd k-sliced %s %s' % (shape, mode))
+
+
 WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]
 
 
@@ -187,7 +212,7 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
 
     yd, dad = dev(y, tdtype), dev(da, tdtype)
     mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    ws = torch.zeros(1024 * C, dtype=torch.float64, device='cuda')
+    ws = torch.zeros(1026 * C, dtype=torch.float64, device='cuda')
     ops.bn_stats(yd, mean, var, ws, M, C)
     lda = C + 16
     A = torch.zeros(M * lda, dtype=tdtype, device='cuda')

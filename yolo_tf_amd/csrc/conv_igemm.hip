@@ -6,17 +6,29 @@
 //   O[m, n] = bias[n] + sum_{tap, c} P[pix(m) + shift(tap), c] * F[n][tap*Cp + c]
 //   GEMM view: M = B*H*W output pixels, N = Nf filters, K = ksize^2 * Cp.
 //
-// Tiling: 256 threads = 4 waves, block tile 128(M) x BN(N), K step = 64 bytes of channels of one
-// tap (32 bf16 / 16 f32).  Both operands are staged global -> registers -> LDS (rows of 64 B +
-// 16 B pad = 80 B: conflict-free ds_read_b128 for the 32x32 MFMA fragments) with a 2-deep LDS
-// ring: the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
-// other LDS buffer after them, one barrier per K step.  Halo / image-border / channel-tail /
-// M-tail elements are zero-filled in registers, so SAME padding costs nothing extra.
-// A = pixels (rows), B = filters (cols): the 32x32 accumulator layout then puts 32 consecutive
-// output channels of one pixel in 32 consecutive lanes -> contiguous 64 B (bf16) / 128 B (f32)
-// store segments.
-// blockIdx -> tile: filter tile fastest, so the blocks an XCD receives (bid % 8) keep re-using
-// the same filter slab from that XCD's private L2 while sweeping M.
+// Structure (one workgroup = 4 waves = a 128(M) x BN(N) output tile, K step = 64 bytes of channels of
+// one tap):
+//   * Operands go HBM/L2 -> LDS by DMA: buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no
+//     VGPR round trip, no ds_write pass).  The DMA writes LDS lane-linearly (wave-uniform base +
+//     lane*16 B), so rows cannot be padded; the b128 fragment reads are kept bank-conflict-free by an
+//     XOR swizzle applied on the SOURCE side: the lane that owns LDS position (row, slot) fetches global
+//     chunk  slot ^ ((row / rows_per_256B) % 4); the fragment reads apply the same involution
+//     (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * SAME padding, image borders, the M tail, filter-row tail and channel tail are all realised by the
+//     buffer descriptor's hardware range check: a lane that must contribute zeros uses an out-of-range
+//     offset and the DMA writes 0 -- no branches, no pointer selects, 32-bit offsets only.  Which of the
+//     9 taps are inside the image for a pixel row is a 9-bit mask computed once per lane.
+//     (The first version computed bounds + 64-bit addresses + tap/ksize divisions per DMA piece and spent
+//     11 VALU + 12 SALU instructions per MFMA: instruction-issue bound at 17 % MFMA utilisation.)
+//   * NSTAGE-deep LDS ring: the DMA of tile t+NSTAGE-1 is issued right after the barrier of tile t and
+//     only tile t's own pieces are waited for (counted s_waitcnt vmcnt(N) + raw s_barrier; a
+//     __syncthreads() would drain every DMA in flight).
+//   * A = pixels (rows), B = filters (cols): the 32x32 accumulator layout puts 32 consecutive output
+//     channels of one pixel in 32 consecutive lanes -> 64 B (bf16) / 128 B (f32) store segments.
+//   * Small M x N grids (13x13 / 26x26 stages at batch 16) slice the K loop over gridDim.y; partial
+//     tiles are accumulated in an f32 workspace with hardware atomics and finished by a tiny kernel.
+//   * blockIdx -> tile: filter tile fastest (the blocks of XCD b%8 keep one filter slab in their L2), or,
+//     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"
 #include <stdlib.h>
 
@@ -24,9 +36,6 @@ template <typename T> struct Mma;
 template <> struct Mma<bf16> {
     static constexpr int KSTEP = 16;
     typedef bf16x8 Frag;
-    static __device__ __forceinline__ Frag load(const bf16 *row, int kk, int lane) {
-        return *reinterpret_cast<const bf16x8 *>(row + kk * 16 + (lane >> 5) * 8);
-    }
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -34,64 +43,80 @@ template <> struct Mma<bf16> {
 template <> struct Mma<float> {
     static constexpr int KSTEP = 2;
     typedef float Frag;
-    static __device__ __forceinline__ Frag load(const float *row, int kk, int lane) {
-        return row[kk * 2 + (lane >> 5)];
-    }
     static __device__ __forceinline__ f32x16 mma(Frag a, Frag b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
     }
 };
 
-// CH = 16-byte chunks per LDS row (K step = CH*16 bytes of channels); SPLITK: gridDim.y slices of the
-// K loop accumulate f32 partial tiles into Oacc with hardware atomics (finished by splitk_finish_kernel)
-template <typename T, int BN, int WGN, int CH, bool SPLITK>
+#define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
+
+template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
-    const T *__restrict__ P, const T *__restrict__ F, const float *__restrict__ bias,
-    T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, int M, int NT) {
+    const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
+    T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
     constexpr int BM = 128;
+    constexpr int CH = 4;                  // 16-byte chunks per tile row
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int BK = CH * VEC;
-    constexpr int LDS = BK + VEC;  // row stride: CH*16 + 16 bytes (80 / 144 B: conflict-free b128 fragment reads)
+    constexpr int BK = CH * VEC;           // 32 bf16 / 16 f32
+    constexpr int ROWB = CH * 16;          // 64 bytes per tile row
+    constexpr int RPL = 256 / ROWB;        // rows per 256-byte LDS bank line
+    constexpr int RPI = 64 / CH;           // rows per DMA instruction (1 KiB)
     constexpr int WGM = 4 / WGN;
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int RPP = 256 / CH;                 // rows covered per pass of the 256 threads
-    constexpr int A_IT = BM / RPP;
-    constexpr int B_IT = (BN + RPP - 1) / RPP;
-    static_assert(TM >= 1 && TN >= 1, "tile");
+    constexpr int A_IT = BM / RPI / 4;     // DMA instructions per wave per tile
+    constexpr int B_PIECES = BN / RPI;
+    constexpr int B_IT = (B_PIECES + 3) / 4;
+    constexpr int LOADS = A_IT + B_IT;     // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
+    constexpr int PAD = KS / 2;
+    constexpr int STAGE = (BM + B_IT * 4 * RPI) * ROWB;
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && TM >= 1 && TN >= 1, "tile");
 
-    __shared__ __attribute__((aligned(16))) T smem[2][(BM + BN) * LDS];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int nt = blockIdx.x % NT, mt = blockIdx.x / NT;
+    int tile = blockIdx.x;
+    if (remap) {   // one contiguous run of tiles per XCD (bijective for any grid size)
+        const int ntile = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = ntile >> 3, r = ntile & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nt = tile % NT, mt = tile / NT;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int chunk = tid % CH, trow = tid / CH;
-    const int Ktot = ksize * ksize * Cp;
-    const int pad = ksize >> 1;
+    const int lrow = lane / CH, lslot = lane % CH;
 
-    int a_h[A_IT], a_w[A_IT];
-    long a_off[A_IT];
+    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
+
+    // per-lane source descriptors: byte offset of (row, swizzled chunk) and the set of taps inside the image
+    unsigned a_voff[A_IT], a_mask[A_IT], a_cb[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        int m = m0 + trow + i * RPP;
+        const int r = (wave * A_IT + i) * RPI + lrow;
+        a_cb[i] = (unsigned)((lslot ^ ((r / RPL) % CH)) * 16);   // byte offset of this lane's chunk inside the K step
+        const int m = m0 + r;
+        unsigned mask = 0;
         if (m < M) {
-            int rem = m % (H * W);
-            a_h[i] = rem / W;
-            a_w[i] = rem - a_h[i] * W;
-        } else {
-            a_h[i] = -100000;
-            a_w[i] = 0;
+            const int rem = m % (H * W);
+            const int h = rem / W, w = rem - h * W;
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                const int hh = h + t / KS - PAD, ww = w + t % KS - PAD;
+                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << t;
+            }
         }
-        a_off[i] = (long)m * ldp;
+        a_mask[i] = mask;
+        a_voff[i] = (unsigned)m * (unsigned)ldp * (unsigned)sizeof(T) + a_cb[i];
     }
-    long b_off[B_IT];
-    bool b_ok[B_IT];
+    unsigned b_voff[B_IT], b_cb[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        int row = trow + i * RPP;
-        int n = n0 + row;
-        b_ok[i] = (row < BN) && (n < Nf);
-        b_off[i] = (long)n * Ktot;
+        const int piece = wave * B_IT + i;
+        const int r = piece * RPI + lrow;
+        b_cb[i] = (unsigned)((lslot ^ ((r / RPL) % CH)) * 16);
+        const int n = n0 + r;
+        const bool ok = piece < B_PIECES && n < Nf;
+        b_voff[i] = ok ? (unsigned)n * (unsigned)(KS * KS * Cp) * (unsigned)sizeof(T) + b_cb[i] : Y2_OOB;
     }
 
     f32x16 acc[TM][TN];
@@ -102,39 +127,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int kpt = (Cp + BK - 1) / BK;  // K tiles per tap
-    const int nk = ksize * ksize * kpt;
-
-    Vec16<T> ra[A_IT], rb[B_IT];
-    auto g_load = [&](int tap, int c0) {
-        const int dh = tap / ksize - pad, dw = tap % ksize - pad;
-        const int c = c0 + chunk * VEC;
-        const bool cok = c < Cp;
-        const long shift = (long)(dh * W + dw) * ldp + c;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
-            int hh = a_h[i] + dh, ww = a_w[i] + dw;
-            bool ok = cok && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            ra[i] = ok ? ld16(P + a_off[i] + shift) : zero16<T>();
-        }
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            bool ok = cok && b_ok[i];
-            rb[i] = ok ? ld16(F + b_off[i] + (long)tap * Cp + c) : zero16<T>();
-        }
-    };
-    auto s_store = [&](int buf) {
-        T *As = smem[buf];
-        T *Bs = smem[buf] + BM * LDS;
-#pragma unroll
-        for (int i = 0; i < A_IT; ++i) st16(As + (trow + i * RPP) * LDS + chunk * VEC, ra[i]);
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
-            int row = trow + i * RPP;
-            if (row < BN) st16(Bs + row * LDS + chunk * VEC, rb[i]);
-        }
-    };
-
+    const int kpt = (Cp + BK - 1) / BK;   // K tiles per tap
+    const int nk = KS * KS * kpt;
     int kt_beg = 0, kt_end = nk;
     if (SPLITK) {
         const int per = (nk + gridDim.y - 1) / gridDim.y;
@@ -142,35 +136,82 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         kt_end = min(nk, kt_beg + per);
         if (kt_beg >= kt_end) return;
     }
-    int tap = kt_beg / kpt, c0 = (kt_beg - tap * kpt) * BK;
-    g_load(tap, c0);
-    s_store(0);
-    __syncthreads();
 
-    for (int kt = kt_beg; kt < kt_end; ++kt) {
-        const int cur = (kt - kt_beg) & 1;
-        const bool more = kt + 1 < kt_end;
-        if (more) {
-            c0 += BK;
-            if (c0 >= Cp) { c0 = 0; ++tap; }
-            g_load(tap, c0);
+    // issue cursor (wave-uniform scalars), NSTAGE-1 tiles ahead of the compute cursor
+    int kt_issue = kt_beg;
+    int i_tap = kt_beg / kpt;
+    int i_c0 = (kt_beg - i_tap * kpt) * BK;
+    int i_dh = i_tap / KS - PAD, i_dw = i_tap % KS - PAD;
+    int i_stage = 0;
+    const unsigned cp_bytes = (unsigned)Cp * (unsigned)sizeof(T);
+    auto issue_next = [&]() {
+        const unsigned tapbit = 1u << i_tap;
+        const unsigned offA = (unsigned)((i_dh * W + i_dw) * ldp + i_c0) * (unsigned)sizeof(T);   // may wrap: added mod 2^32
+        const unsigned offB = (unsigned)(i_tap * Cp + i_c0) * (unsigned)sizeof(T);
+        const unsigned c0b = (unsigned)i_c0 * (unsigned)sizeof(T);
+        unsigned char *As = smem + i_stage * STAGE;
+        unsigned char *Bs = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) {
+            bool ok = (a_mask[i] & tapbit) != 0;
+            if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
+            const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
         }
-        const T *As = smem[cur] + (wm * TM * 32 + (lane & 31)) * LDS;
-        const T *Bs = smem[cur] + (BM + wn * TN * 32 + (lane & 31)) * LDS;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) {
+            unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
+            if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
+        }
+        ++kt_issue;
+        i_stage = (i_stage + 1 == NSTAGE) ? 0 : i_stage + 1;
+        i_c0 += BK;
+        if (i_c0 >= Cp) {
+            i_c0 = 0;
+            ++i_tap;
+            if (++i_dw > PAD) { i_dw = -PAD; ++i_dh; }
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (kt_issue < kt_end) issue_next();
+
+    // fragment read addressing: row i = lane&31 (+32 per MFMA tile); 32 rows = a whole number of swizzle periods
+    const int frow = lane & 31;
+    const int fsw = (frow / RPL) % CH;
+    int c_stage = 0;
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        // wait for tile kt only: up to NSTAGE-2 younger tiles stay in flight across the barrier
+        const int ahead = min(NSTAGE - 2, kt_issue - 1 - kt);
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // tile kt complete in LDS for every wave; tile kt-1's buffer is free
+        if (kt_issue < kt_end) issue_next();
+        const unsigned char *As = smem + c_stage * STAGE + (wm * TM * 32 + frow) * ROWB;
+        const unsigned char *Bs = smem + c_stage * STAGE + (BM + wn * TN * 32 + frow) * ROWB;
+        c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
 #pragma unroll
         for (int kk = 0; kk < BK / Mma<T>::KSTEP; ++kk) {
             typename Mma<T>::Frag af[TM], bf[TN];
+            int boff;
+            if constexpr (sizeof(T) == 2) {
+                const int q = kk * 2 + (lane >> 5);            // 16-byte chunk holding this lane's 8 k values
+                boff = (q ^ fsw) * 16;
+            } else {
+                const int e = kk * 2 + (lane >> 5);            // float index inside the row
+                boff = (((e >> 2) ^ fsw) * 16) + (e & 3) * 4;
+            }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Mma<T>::load(As + i * 32 * LDS, kk, lane);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Mma<T>::load(Bs + j * 32 * LDS, kk, lane);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
         }
-        if (more) s_store(cur ^ 1);
-        __syncthreads();
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -205,18 +246,19 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
     }
 }
 
-// number of K slices: aim at >= 3 resident blocks per CU (register-limited occupancy of the 128-wide
-// tile) when the M x N tile grid alone cannot fill 256 CUs, keeping >= 8 K tiles per slice
-struct Tune { int ch; int target_blocks; };
+struct Tune { int target_blocks; int stages; int remap; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{8, 512};
-        if (const char *e = getenv("YOLO2_IGEMM_CH")) v.ch = atoi(e) == 4 ? 4 : 8;
+        Tune v{512, 3, -1};
         if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_STAGES")) v.stages = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
         return v;
     }();
     return t;
 }
+// number of K slices: when the M x N tile grid alone cannot fill 256 CUs with ~2-3 resident workgroups
+// each, slice K so that it does, keeping >= 8 K tiles per slice
 static int choose_ksplit(int tiles, int nk, int target) {
     if (target <= 0 || tiles * 3 >= target * 2 || nk < 32) return 1;
     int ks = (target + tiles - 1) / tiles;
@@ -225,38 +267,60 @@ static int choose_ksplit(int tiles, int nk, int target) {
     return ks < 1 ? 1 : ks;
 }
 
+#define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, gridv)                                                          \
+    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv><<<gridv, 256, 0, st>>>(                                  \
+        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap)
+#define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, gridv)                                   \
+    do {                                                                               \
+        if (ksize == 3) {                                                              \
+            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, true, gridv);               \
+            else Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, false, gridv);                    \
+        } else {                                                                       \
+            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, true, gridv);               \
+            else Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, false, gridv);                    \
+        }                                                                              \
+    } while (0)
+
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
                        int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
+    constexpr int BK = 4 * VEC;
+    const Tune &tu = tune();
+    const unsigned p_bytes = (unsigned)((size_t)M * ldp * sizeof(T));
+    const unsigned f_bytes = (unsigned)((size_t)Nf * ksize * ksize * Cp * sizeof(T));
+    const bool ctail = (Cp % BK) != 0;
+    // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
+    const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
     if (Nf > 64) {
         const int NT = cdiv(Nf, 128);
-        const Tune &tu = tune();
-        const int CHsel = (Cp >= 8 * VEC) ? tu.ch : 4;
-        const int nk = ksize * ksize * cdiv(Cp, CHsel * VEC);
+        const int nk = ksize * ksize * cdiv(Cp, BK);
         int ks = ws ? choose_ksplit(MT * NT, nk, tu.target_blocks) : 1;
         if (ks > 1 && (size_t)M * Nf * sizeof(float) > ws_bytes) ks = 1;
         if (ks > 1) {
             if (hipMemsetAsync(ws, 0, (size_t)M * Nf * sizeof(float), st) != hipSuccess) return 1;
             dim3 grid(MT * NT, ks);
-            if (CHsel == 8)
-                conv_igemm_kernel<T, 128, 2, 8, true><<<grid, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
-            else
-                conv_igemm_kernel<T, 128, 2, 4, true><<<grid, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+            if (tu.stages == 4) Y2_IGEMM_KS_CT(128, 2, 4, true, grid);
+            else if (tu.stages == 2) Y2_IGEMM_KS_CT(128, 2, 2, true, grid);
+            else Y2_IGEMM_KS_CT(128, 2, 3, true, grid);
             long total = (long)M * Nf;
             int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo);
-        } else if (CHsel == 8) {
-            conv_igemm_kernel<T, 128, 2, 8, false><<<MT * NT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
         } else {
-            conv_igemm_kernel<T, 128, 2, 4, false><<<MT * NT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, NT);
+            ws = nullptr;
+            dim3 grid(MT * NT);
+            if (tu.stages == 4) Y2_IGEMM_KS_CT(128, 2, 4, false, grid);
+            else if (tu.stages == 2) Y2_IGEMM_KS_CT(128, 2, 2, false, grid);
+            else Y2_IGEMM_KS_CT(128, 2, 3, false, grid);
         }
-    } else if (Nf > 32) {
-        conv_igemm_kernel<T, 64, 1, 4, false><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
     } else {
-        conv_igemm_kernel<T, 32, 1, 4, false><<<MT, 256, 0, st>>>((const T *)P, (const T *)F, bias, (T *)O, nullptr, H, W, Cp, ldp, Nf, ldo, ksize, M, 1);
+        const int NT = 1;
+        ws = nullptr;
+        dim3 grid(MT);
+        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, false, grid);
+        else Y2_IGEMM_KS_CT(32, 1, 3, false, grid);
     }
     return 0;
 }
@@ -268,8 +332,11 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         return YOLO2_E_ARG;
     }
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
-    if ((long)B * H * W * (long)(ldp > ldo ? ldp : ldo) >= (1L << 31) || Cp % vec || ldp % vec || ((uintptr_t)P & 15) || ((uintptr_t)F & 15)) {
-        yolo2_set_error("%s: argument check failed: size / alignment (channels must be a multiple of %d)", fn, vec);
+    const size_t esz = dtype == YOLO2_BF16 ? 2 : 4;
+    // the DMA path addresses both operands with 32-bit byte offsets below 2^31
+    if ((size_t)B * H * W * (size_t)(ldp > ldo ? ldp : ldo) * esz >= (1ull << 31) || (size_t)Nf * ksize * ksize * Cp * esz >= (1ull << 31) ||
+        Cp % vec || ldp % vec || ((uintptr_t)P & 15) || ((uintptr_t)F & 15)) {
+        yolo2_set_error("%s: argument check failed: operand >= 2 GiB or misaligned (channels must be a multiple of %d)", fn, vec);
         return YOLO2_E_ARG;
     }
     int rc = 0;

@@ -115,12 +115,25 @@ __device__ __forceinline__ void block_colsum_store(const float (&part)[K][N], co
     }
 }
 
-// K = 2: sum x and sum x^2 (single pass; the f64 finalisation forms E[x^2] - mean^2);  K = 1: sum x
+// K = 2: single-pass moments, SHIFTED by the channel's first sample s = X[0][c]: the partials are
+// sum (x-s) and sum (x-s)^2, so the f64 finalisation's E[d^2] - E[d]^2 cancels against (mean-s)^2 ~ var
+// instead of mean^2 (plain E[x^2]-mean^2 loses the variance when |mean| >> std, e.g. few samples per
+// channel).  Block 0 also stores s as a third row of the partial buffer.   K = 1: plain column sum.
 template <typename T, int K>
 __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, float *__restrict__ part) {
     constexpr int N = Vec16<T>::N;
     RowMap rm(C, N);
-    float acc[K][N];
+    float acc[K][N], sh[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) sh[j] = 0.f;
+    if (K == 2 && rm.active) {
+        Vec16<T> v0 = ld16(X + rm.cg * N);
+#pragma unroll
+        for (int j = 0; j < N; ++j) sh[j] = v0.get(j);
+        if (blockIdx.x == 0 && rm.rs == 0)
+#pragma unroll
+            for (int j = 0; j < N; ++j) part[(long)2 * gridDim.x * C + rm.cg * N + j] = sh[j];
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, in
             Vec16<T> v = ld16(X + r * ld + rm.cg * N);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float x = v.get(j);
+                float x = v.get(j) - sh[j];
                 acc[0][j] += x;
                 if (K == 2) acc[K - 1][j] += x * x;
             }
@@ -161,8 +174,9 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float *__res
 #pragma unroll
         for (int k = 0; k < K; ++k) t[k] = red[k][0][col] + red[k][1][col] + red[k][2][col] + red[k][3][col];
         if (FIN == 0) {
-            double mean = t[0] / (double)M;
-            double var = t[K - 1] / (double)M - mean * mean;
+            double dm = t[0] / (double)M;                       // mean of (x - shift)
+            double var = t[K - 1] / (double)M - dm * dm;
+            double mean = (double)part[(long)2 * nb * C + c] + dm;
             o0[c] = (float)mean;
             o1[c] = (float)(var > 0.0 ? var : 0.0);
         } else if (FIN == 1) {

@@ -137,7 +137,7 @@ class Engine(object):
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
         self.conv_ws = torch.zeros(min(max(max_y, 1), 8 * 1024 * 1024), dtype=torch.float32, device=dev)
-        self.ws = torch.zeros(1024 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
+        self.ws = torch.zeros(1026 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
             self.dy_scratch = torch.zeros(max_y, dtype=T, device=dev)
             self.tmp_grad = {}
