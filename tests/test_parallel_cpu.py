@@ -1,0 +1,130 @@
+"""Data-parallel path on CPU: bucket construction, the reverse-order arena layout that makes buckets
+complete front-to-back during backward, and a world_size-2 gloo run of GradReducer (the same code
+path that drives RCCL on the GPUs, minus the side stream)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _graph(inference='darknet'):
+    from yolo_tf_amd import graph as G
+    from yolo_tf_amd.model.yolo2 import inference as inf
+    g = G.Graph()
+    x = G.placeholder(g, 'image', 416, 416)
+    getattr(inf, inference)(x, 20, 5, training=True)
+    return g
+
+
+def test_arena_layout_is_reverse_creation_order_and_backward_monotone():
+    from yolo_tf_amd.engine import layout_params, layer_end_offsets
+    g = _graph()
+    offsets, total = layout_params(g)
+    assert total >= 67_100_000 and total % 4 == 0
+    spans = sorted(offsets.values())
+    assert spans[0][0] == 0
+    for (o1, n1), (o2, _) in zip(spans, spans[1:]):
+        assert o1 + (n1 + 3) // 4 * 4 == o2 and o2 % 4 == 0          # contiguous, 16-byte aligned
+    # the last layer's variables come first: their gradients are the first to be final
+    assert offsets['yolo2_darknet/conv/biases'][0] < offsets['yolo2_darknet/conv20/weights'][0] < offsets['yolo2_darknet/conv0/weights'][0]
+    ends = layer_end_offsets(g, offsets)
+    seq = [ends[op['name']] for op in reversed(g.ops) if op['kind'] == 'conv']
+    assert seq == sorted(seq) and seq[-1] == total
+
+
+def test_buckets_partition_the_arena_at_variable_boundaries():
+    from yolo_tf_amd.engine import layout_params
+    from yolo_tf_amd.parallel import make_buckets
+    offsets, total = layout_params(_graph())
+    for mb in (1, 16, 64, 1024):
+        buckets = make_buckets(offsets.values(), total, int(mb * 1024 * 1024 / 4))
+        assert buckets[0][0] == 0 and buckets[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
+        bounds = {o + (n + 3) // 4 * 4 for o, n in offsets.values()} | {total}
+        assert all(e in bounds for _, e in buckets)
+        assert all(e - s >= mb * 1024 * 1024 / 4 for s, e in buckets[:-1])
+    assert len(make_buckets(offsets.values(), total, 16 * 1024 * 1024)) >= 3   # 64 MiB buckets: several all-reduces in flight
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from yolo_tf_amd.parallel import GradReducer, init_distributed
+    r, _, w = init_distributed(backend='gloo')
+    assert (r, w) == (rank, world)
+    sizes = [400, 250, 7, 1000, 364, 3]                     # variables of a toy arena, every one 4-aligned in the arena
+    offs, off = [], 0
+    for n in sizes:
+        offs.append((off, n))
+        off += (n + 3) // 4 * 4
+    grads = torch.arange(off, dtype=torch.float32) * (rank + 1)
+    red = GradReducer(grads, offs, bucket_mb=300 * 4 / (1024 * 1024))          # ~300-element buckets -> several buckets
+    assert len(red.buckets) >= 3
+    for step in range(2):                                   # reusable across steps
+        if step:
+            grads.copy_(torch.arange(off, dtype=torch.float32) * (rank + 1))
+        red.begin()
+        launched = []
+        for end in sorted(o + (n + 3) // 4 * 4 for o, n in offs):      # backward finishing layer after layer
+            red.ready_upto(end)
+            launched.append(red.next_bucket)
+        assert launched == sorted(launched)
+        red.finish()
+        expect = torch.arange(off, dtype=torch.float32) * sum(range(1, world + 1))
+        assert torch.equal(grads, expect), (rank, step)
+    # folded averaging: the optimizer's gscale = 1/world turns the sum into the mean
+    assert torch.allclose(grads / world, torch.arange(off, dtype=torch.float32) * (world + 1) / 2)
+    if rank == 0:
+        open(out, 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_gloo_world2(tmp_path):
+    out = str(tmp_path / 'ok')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == 'ok'
+
+
+def test_single_process_reducer_is_a_noop():
+    from yolo_tf_amd.parallel import GradReducer
+    g = torch.ones(100)
+    red = GradReducer(g, [(0, 100)], bucket_mb=1)
+    red.begin()
+    red.ready_upto(100)
+    red.finish()
+    assert torch.equal(g, torch.ones(100))
+
+
+def test_host_side_helpers():
+    """config overlay order, cell-grid asserts, lr schedule -- host logic shared by train.py / detect.py."""
+    import configparser
+    from yolo_tf_amd import utils
+    from yolo_tf_amd.optim import learning_rate_fn
+    cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo2', 'darknet-20.ini')], '/tmp/base')
+    assert cfg.get('cache', 'names') == 'config/names/20' and cfg.get('yolo2', 'anchors').endswith('voc.tsv')   # later file wins
+    assert utils.get_logdir(cfg) == '/tmp/base/yolo2/darknet/20' and utils.get_cachedir(cfg) == '/tmp/base/cache/20'
+    assert utils.calc_cell_width_height(cfg, 416, 416) == (13, 13) and utils.get_downsampling(cfg) == (32, 32)
+    with pytest.raises(AssertionError):
+        utils.calc_cell_width_height(cfg, 400, 416)
+    lr = learning_rate_fn(cfg, 1.0)
+    assert lr(0) == 1.0 and lr(99999) == 1.0 and abs(lr(100000) - 0.96) < 1e-12 and abs(lr(250000) - 0.96 ** 2) < 1e-12
+    cfg.remove_section('exponential_decay')
+    assert learning_rate_fn(cfg, 0.5)(10 ** 6) == 0.5
+    anchors = utils.read_anchors(os.path.join(ROOT, 'config', 'yolo2', 'anchors', 'voc.tsv'))
+    assert anchors.shape == (5, 2) and np.allclose(anchors[0], [1.08, 1.19])

@@ -26,6 +26,27 @@ LEAKY_ALPHA = 0.1    # model/yolo/function.py:21
 _DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f32': torch.float32, 'float32': torch.float32}
 
 
+def layout_params(graph):
+    """Flat f32 arena layout of the trainable variables: REVERSE creation order (the last layer first), every
+    variable 16-byte aligned.  Returns ({name: (offset, size)}, total elements).  Pure host logic."""
+    offsets, off = {}, 0
+    for v in reversed(graph.trainable()):
+        offsets[v.name] = (off, v.size)
+        off += (v.size + 3) // 4 * 4
+    return offsets, off
+
+
+def layer_end_offsets(graph, offsets):
+    """For every conv op: the arena offset below which all gradients are final once that op's backward has
+    run (backward visits ops in reverse order, so these ends grow monotonically)."""
+    ends = {}
+    for op in graph.ops:
+        if op['kind'] == 'conv':
+            names = [op['weights'].name] + [op[k].name for k in ('gamma', 'beta', 'biases') if k in op]
+            ends[op['name']] = max(offsets[n][0] + (offsets[n][1] + 3) // 4 * 4 for n in names)
+    return ends
+
+
 class Engine(object):
     def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None):
         if not torch.cuda.is_available():
@@ -45,13 +66,8 @@ class Engine(object):
     # ---------------------------------------------------------------- variables
     def _alloc_variables(self):
         g = self.graph
-        train = list(reversed(g.trainable()))
         other = [v for v in g.variables.values() if not v.trainable]
-        self.param_offsets = {}
-        off = 0
-        for v in train:
-            self.param_offsets[v.name] = (off, v.size)
-            off += (v.size + 3) // 4 * 4         # keep every variable 16-byte aligned
+        self.param_offsets, off = layout_params(g)
         self.n_params = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.grads = torch.zeros(off, dtype=torch.float32, device=self.device) if self.training else None

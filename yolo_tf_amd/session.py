@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .engine import Engine
+from .engine import Engine, layer_end_offsets
 from .graph import pad8
 from .model.yolo2 import OBJECTIVE_KEYS
 from .optim import Optimizer, learning_rate_fn
@@ -44,13 +44,8 @@ class TrainSession(object):
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
         self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb) if world_size > 1 else None
-        # end offset (in the flat arena) of everything a conv layer owns: reverse creation order means
-        # offsets below it are complete once that layer's backward has run
-        self._layer_end = {}
-        for op in e.graph.ops:
-            if op['kind'] == 'conv':
-                names = [op['weights'].name] + [op[k].name for k in ('gamma', 'beta', 'biases') if k in op]
-                self._layer_end[op['name']] = max(e.param_offsets[n][0] + (e.param_offsets[n][1] + 3) // 4 * 4 for n in names)
+        # arena offset below which every gradient is final once a given layer's backward has run
+        self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
 
     def upload_labels(self, labels):
         for dst, src in zip(self.labels, labels):
