@@ -78,6 +78,9 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
  * (per-block partial sums; any content) */
 int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C,
                    int dtype, void *stream);
+/* yolo2_bn_stats + yolo2_bn_ema in one pass (the moving-average update rides in the finalisation kernel) */
+int yolo2_bn_stats_ema(const void *Y, float *mean, float *var, float *moving_mean, float *moving_var,
+                       double decay, double *ws, long M, int C, int dtype, void *stream);
 /* moving -= f32(1-decay)*(moving-batch)   (assign_moving_average, decay 0.999; 1-decay is formed in
  * double and then rounded, as TF's Python side does) */
 int yolo2_bn_ema(float *moving_mean, float *moving_var, const float *mean, const float *var,

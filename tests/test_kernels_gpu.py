@@ -223,6 +223,10 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
     ops.bn_leaky_bwd_apply(dad, C, yd, mean, var, dev(gamma), dev(beta), dg, db, dY, M, C, 1e-5, 0.1)
     mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
     ops.bn_ema(mm, mv, mean, var, C, 0.999)
+    mm2, mv2, mean2, var2 = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_stats_ema(yd, mean2, var2, mm2, mv2, 0.999, ws, M, C)          # fused statistics + moving-average update
+    torch.cuda.synchronize()
+    assert torch.equal(mean2, mean) and torch.equal(var2, var) and torch.equal(mm2, mm) and torch.equal(mv2, mv)
     torch.cuda.synchronize()
     assert_close(host(mean), mean_r, 1e-5, 'mean')
     assert_close(host(var), var_r, 1e-5, 'var')

@@ -30,6 +30,7 @@ SIGNATURES = {
     'yolo2_conv2d_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],
+    'yolo2_bn_stats_ema': [_p, _p, _p, _p, _p, ctypes.c_double, _p, _l, _i, _i, _p],
     'yolo2_bn_ema': [_p, _p, _p, _p, _i, ctypes.c_double, _p],
     'yolo2_bn_leaky': [_p, _p, _p, _p, _p, _p, _l, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _f, _i, _p],

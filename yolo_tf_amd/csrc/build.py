@@ -44,6 +44,8 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        import ctypes
+        ctypes.CDLL(LIB)          # fails here (not on the GPU box) if any symbol is unresolved
     return LIB
 
 

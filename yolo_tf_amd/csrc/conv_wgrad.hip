@@ -5,63 +5,106 @@
 //   dW[tap][c][n] += sum_{m in pixel range} X[pix(m) + shift(tap), c] * dY[m, n]
 //   GEMM view per tap: rows = Cin, cols = Cout, reduction = B*H*W pixels.
 //
-// The reduction index (pixels) is the strided one in NHWC for BOTH operands, so the MFMA
-// fragments need a transpose.  Tiles are staged pixel-major [pixel][channel] (exactly as they
-// lie in HBM, 16-B coalesced loads) and the bf16 fragments are gathered with the gfx950
-// hardware transpose read ds_read_b64_tr_b16: each 16-lane group reads a 4-pixel x 16-channel
-// block and every lane receives 4 pixels of its own channel; two reads give the 8 reduction
-// slots of v_mfma_f32_32x32x16_bf16.  Rows are padded by 64 B so the 4 pixel rows of a group
-// land on disjoint banks.  The f32 parity path uses v_mfma_f32_32x32x2_f32, whose operands are
-// one scalar per lane (plain ds_read_b32, lanes along channels, conflict-free).
+// The reduction index (pixels) is the strided one in NHWC for BOTH operands, so the MFMA fragments
+// need a transpose.  Tiles are staged pixel-major [pixel][channel] exactly as they lie in HBM, by DMA
+// (buffer_load_dwordx4 ... lds, 1 KiB = a few whole pixel rows per wave-instruction), and the bf16
+// fragments are gathered with the gfx950 hardware transpose read ds_read_b64_tr_b16: each 16-lane
+// group reads a 4-pixel x 16-channel block and every lane receives 4 pixels of its own channel; two
+// reads give the 8 reduction slots of v_mfma_f32_32x32x16_bf16 (layout pinned on hardware by
+// tests/test_kernels_gpu.py::test_tr16_layout).  DMA destinations are lane-linear, so instead of
+// padding rows the 16-byte chunk index is XOR-ed with 4*(pixel_row_in_bank_line) on the source side and
+// in the reads: the 4 pixel rows a transpose read touches land on 4 disjoint bank quarters
+// (SQ_LDS_BANK_CONFLICT = 0).  The f32 parity path uses v_mfma_f32_32x32x2_f32 (one scalar per lane,
+// plain ds_read_b32, lanes along channels).
+// Image borders / SAME padding / tails: the X lane whose shifted pixel falls outside the image, and every
+// lane beyond the pixel range or channel count, uses an out-of-range buffer offset -> the DMA writes 0.
+// 3-stage LDS ring with counted vmcnt + raw s_barrier as in conv_igemm.hip.
 // Grid: x = (tap, c-tile, n-tile), y = pixel-range split; partial tiles are accumulated into the
 // zero-initialised f32 dW with hardware f32 atomics (lanes run along n -> coalesced).
 #include "common.h"
+#include <stdlib.h>
+
+#define Y2_OOB 0x80000000u
 
 template <typename T, int BC, int BNN, int VARIANT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    const T *__restrict__ X, const T *__restrict__ dY, float *__restrict__ dW, int H, int W,
-    int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk) {
+    const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W,
+    int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap) {
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;  // pixels per reduction tile
-    constexpr int PADE = 64 / sizeof(T);           // 64-byte row pad
-    constexpr int LX = BC + PADE, LY = BNN + PADE;
-    constexpr int CPRX = BC / VEC, CPRY = BNN / VEC;
-    constexpr int RPX = 256 / CPRX, RPY = 256 / CPRY;  // rows covered per pass
-    constexpr int XI = BKP / RPX, YI = BKP / RPY;
-    static_assert(XI >= 1 && YI >= 1, "tile too narrow for this thread mapping");
-    constexpr int TM = BC / 64, TN = BNN / 64;  // 2x2 waves, each (BC/2) x (BNN/2)
+    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;      // pixels per reduction tile
+    constexpr int XROWB = BC * sizeof(T), YROWB = BNN * sizeof(T);   // bytes per pixel row of a tile
+    constexpr int XCH = XROWB / 16, YCH = YROWB / 16;  // 16-byte chunks per row
+    constexpr int XRPI = 1024 / XROWB, YRPI = 1024 / YROWB;           // pixel rows per DMA instruction
+    constexpr int X_IT = BKP / XRPI / 4, Y_IT = BKP / YRPI / 4;       // DMA instructions per wave per tile
+    constexpr int LOADS = X_IT + Y_IT;
+    constexpr int NSTAGE = 3;
+    constexpr int XBYTES = BKP * XROWB, STAGE = XBYTES + BKP * YROWB;
+    constexpr int TM = BC / 64, TN = BNN / 64;         // 2x2 waves, each (BC/2) x (BNN/2)
     constexpr int KSTEP = sizeof(T) == 2 ? 16 : 2;
+    static_assert(X_IT >= 1 && Y_IT >= 1, "tile too small for one DMA piece per wave");
+    // swizzle: chunk ^= 4 * ((row / rows_per_bank_line) % (row_bytes / 64)); identity for rows >= 512 B
+    constexpr int XRPL = XROWB >= 256 ? 1 : 256 / XROWB, XSWM = XROWB >= 512 ? 1 : XROWB / 64;
+    constexpr int YRPL = YROWB >= 256 ? 1 : 256 / YROWB, YSWM = YROWB >= 512 ? 1 : YROWB / 64;
 
-    __shared__ __attribute__((aligned(16))) T smem[2][BKP * (LX + LY)];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int bx = blockIdx.x;
+    // Block -> (tile, pixel range).  All tiles (tap, c-tile, n-tile) of one pixel range read the same X / dY
+    // rows, so they are placed on ONE XCD (the dispatcher puts block b on XCD b % 8; observed, speed only):
+    // XCD x walks the pixel ranges y = x, x+8, ... and for each runs all tiles back to back, which keeps a
+    // range's rows in that XCD's private L2 instead of fetching them into up to 8 L2s.
+    const int ntiles = ksize * ksize * CT * NT;
+    int bx, by;
+    if (remap) {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        by = (idx / ntiles) * 8 + xcd;
+        bx = idx % ntiles;
+    } else {
+        bx = blockIdx.x % ntiles;
+        by = blockIdx.x / ntiles;
+    }
     const int nt = bx % NT; bx /= NT;
     const int ct = bx % CT;
     const int tap = bx / CT;
     const int pad = ksize >> 1;
     const int dh = tap / ksize - pad, dw = tap % ksize - pad;
     const int c0 = ct * BC, n0 = nt * BNN;
-    const int mbeg = blockIdx.y * mchunk;
+    const int mbeg = by * mchunk;
     const int mend = min(M, mbeg + mchunk);
     if (mbeg >= mend) return;
 
-    const int xc = (tid % CPRX) * VEC, xr = tid / CPRX;
-    const int yc = (tid % CPRY) * VEC, yr = tid / CPRY;
-    const bool xc_ok = c0 + xc < Cin, yc_ok = n0 + yc < Cout;
-    // NB lanes beyond Cin/Cout inside the padded pixel stride read zeros (padding contract), but
-    // lanes beyond ldx/ldy must not be touched:
-    const bool xc_in = c0 + xc < ldx, yc_in = n0 + yc < ldy;
+    // the dY descriptor ends at the last pixel of this block's range: rows beyond it read as zero
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), 0, x_bytes, 0x00020000);
+    const unsigned y_lim = min(y_bytes, (unsigned)mend * (unsigned)ldy * (unsigned)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dY), 0, y_lim, 0x00020000);
 
-    int xh[XI], xw[XI];
+    // per-lane DMA descriptors
+    unsigned x_voff[X_IT], y_voff[Y_IT];
+    int xh[X_IT], xw[X_IT], xm[X_IT];
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        int m = mbeg + xr + i * RPX;
-        int rem = m % (H * W);
-        xh[i] = rem / W;
-        xw[i] = rem - xh[i] * W;
+    for (int i = 0; i < X_IT; ++i) {
+        const int r = (wave * X_IT + i) * XRPI + lane / XCH;                 // pixel row inside the tile
+        const int chunk = (lane % XCH) ^ (((r / XRPL) % XSWM) * 4);          // source-side swizzle
+        const int c = c0 + chunk * VEC;
+        const int m = mbeg + r;
+        xm[i] = m;
+        const int rem = m % (H * W);
+        xh[i] = rem / W + dh;                                                // shifted coordinates of this row's pixel
+        xw[i] = rem % W + dw;
+        // channel chunk beyond Cin (or beyond the padded pixel stride): permanently out of range
+        x_voff[i] = (c < Cin && c < ldx) ? (unsigned)((long)(m + dh * W + dw) * ldx + c) * (unsigned)sizeof(T) : Y2_OOB;
     }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+        const int r = (wave * Y_IT + i) * YRPI + lane / YCH;
+        const int chunk = (lane % YCH) ^ (((r / YRPL) % YSWM) * 4);
+        const int n = n0 + chunk * VEC;
+        y_voff[i] = (n < Cout && n < ldy) ? (unsigned)((long)(mbeg + r) * ldy + n) * (unsigned)sizeof(T) : Y2_OOB;
+    }
+    const unsigned x_step = (unsigned)BKP * (unsigned)ldx * (unsigned)sizeof(T);
+    const unsigned y_step = (unsigned)BKP * (unsigned)ldy * (unsigned)sizeof(T);
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -71,68 +114,71 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Vec16<T> rx[XI], ry[YI];
-    auto g_load = [&](int mt0) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) {
-            int m = mt0 + xr + i * RPX;
-            int hh = xh[i] + dh, ww = xw[i] + dw;
-            bool ok = (xc_ok && xc_in) && m < mend && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
-            rx[i] = ok ? ld16(X + ((long)m + dh * W + dw) * ldx + c0 + xc) : zero16<T>();
-            // advance this slot's (h, w) by BKP pixels for the next tile
-            xw[i] += BKP;
-            while (xw[i] >= W) { xw[i] -= W; xh[i] += 1; }
-            while (xh[i] >= H) xh[i] -= H;
-        }
-#pragma unroll
-        for (int i = 0; i < YI; ++i) {
-            int m = mt0 + yr + i * RPY;
-            bool ok = (yc_ok && yc_in) && m < mend;
-            ry[i] = ok ? ld16(dY + (long)m * ldy + n0 + yc) : zero16<T>();
-        }
-    };
-    auto s_store = [&](int buf) {
-        T *Xs = smem[buf];
-        T *Ys = smem[buf] + BKP * LX;
-#pragma unroll
-        for (int i = 0; i < XI; ++i) st16(Xs + (xr + i * RPX) * LX + xc, rx[i]);
-#pragma unroll
-        for (int i = 0; i < YI; ++i) st16(Ys + (yr + i * RPY) * LY + yc, ry[i]);
-    };
-
     const int nk = (mend - mbeg + BKP - 1) / BKP;
-    g_load(mbeg);
-    s_store(0);
-    __syncthreads();
+    int kt_issue = 0, i_stage = 0;
+    auto issue_next = [&]() {
+        unsigned char *Xs = smem + i_stage * STAGE;
+        unsigned char *Ys = Xs + XBYTES;
+#pragma unroll
+        for (int i = 0; i < X_IT; ++i) {
+            const bool ok = xm[i] < mend && (unsigned)xh[i] < (unsigned)H && (unsigned)xw[i] < (unsigned)W;
+            const unsigned voff = ok ? x_voff[i] : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(Xs + (wave * X_IT + i) * 1024), 16, voff, 0, 0, 0);
+            // advance this row slot by BKP pixels
+            x_voff[i] += x_step;           // OOB + k*step stays >= 2^31 for every step taken (operands < 2^31 bytes)
+            xm[i] += BKP;
+            xw[i] += BKP;
+            while (xw[i] - dw >= W) { xw[i] -= W; xh[i] += 1; }
+            while (xh[i] - dh >= H) xh[i] -= H;
+        }
+#pragma unroll
+        for (int i = 0; i < Y_IT; ++i) {
+            const unsigned yv = y_voff[i];   // (a temporary: hipcc 7.2 drops the kernel's host stub when the captured array element is passed directly)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void *)(Ys + (wave * Y_IT + i) * 1024), 16, yv, 0, 0, 0);
+            y_voff[i] += y_step;
+        }
+        ++kt_issue;
+        i_stage = (i_stage + 1 == NSTAGE) ? 0 : i_stage + 1;
+    };
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (kt_issue < nk) issue_next();
 
     const int g = lane >> 4, t = lane & 15;
+    int c_stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) g_load(mbeg + (kt + 1) * BKP);
-        const T *Xs = smem[cur];
-        const T *Ys = smem[cur] + BKP * LX;
+        const int ahead = min(NSTAGE - 2, kt_issue - 1 - kt);
+        if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt_issue < nk) issue_next();
+        const unsigned char *Xs = smem + c_stage * STAGE;
+        const unsigned char *Ys = Xs + XBYTES;
+        c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
 #pragma unroll
         for (int ks = 0; ks < BKP / KSTEP; ++ks) {
             if constexpr (sizeof(T) == 2) {
                 bf16x8 af[TM], bf[TN];
                 if constexpr (VARIANT == 0) {
-                    // hardware transpose read: lane (g,t) supplies the address of pixel row (t>>2),
-                    // channel quad (t&3) of its group's 4x16 block and receives 4 pixels of channel t
+                    // hardware transpose read: lane (g,t) supplies the address of pixel row (t>>2), channel quad
+                    // (t&3) of its group's 4x16 block and receives 4 pixels of channel t
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t >> 2);
-                        const int co = 16 * (g & 1) + 4 * (t & 3);
+                        const int co = 16 * (g & 1) + 4 * (t & 3);               // channel offset inside a 32-wide MFMA tile
+                        const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
-                            const bf16 *p = (const bf16 *)Xs + px * LX + (wm * TM + i) * 32 + co;
+                            const int ch = (wm * TM + i) * 32 + co;
+                            const unsigned char *p = Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1);
                             s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
                             bf16x4 b = __builtin_bit_cast(bf16x4, v);
                             af[i][4 * r + 0] = b[0]; af[i][4 * r + 1] = b[1]; af[i][4 * r + 2] = b[2]; af[i][4 * r + 3] = b[3];
                         }
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
-                            const bf16 *p = (const bf16 *)Ys + px * LY + (wn * TN + j) * 32 + co;
+                            const int ch = (wn * TN + j) * 32 + co;
+                            const unsigned char *p = Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1);
                             s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
                             bf16x4 b = __builtin_bit_cast(bf16x4, v);
                             bf[j][4 * r + 0] = b[0]; bf[j][4 * r + 1] = b[1]; bf[j][4 * r + 2] = b[2]; bf[j][4 * r + 3] = b[3];
@@ -143,10 +189,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int px = ks * 16 + 8 * (lane >> 5) + e;
+                        const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) af[i][e] = ((const bf16 *)Xs)[px * LX + (wm * TM + i) * 32 + (lane & 31)];
+                        for (int i = 0; i < TM; ++i) {
+                            const int ch = (wm * TM + i) * 32 + (lane & 31);
+                            af[i][e] = *reinterpret_cast<const bf16 *>(Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1));
+                        }
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) bf[j][e] = ((const bf16 *)Ys)[px * LY + (wn * TN + j) * 32 + (lane & 31)];
+                        for (int j = 0; j < TN; ++j) {
+                            const int ch = (wn * TN + j) * 32 + (lane & 31);
+                            bf[j][e] = *reinterpret_cast<const bf16 *>(Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1));
+                        }
                     }
                 }
 #pragma unroll
@@ -157,10 +210,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             } else {
                 float af[TM], bf[TN];
                 const int px = ks * 2 + (lane >> 5);
+                const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = ((const float *)Xs)[px * LX + (wm * TM + i) * 32 + (lane & 31)];
+                for (int i = 0; i < TM; ++i) {
+                    const int ch = (wm * TM + i) * 32 + (lane & 31);
+                    af[i] = *reinterpret_cast<const float *>(Xs + px * XROWB + (((ch >> 2) ^ xsw) << 4) + ((ch & 3) << 2));
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = ((const float *)Ys)[px * LY + (wn * TN + j) * 32 + (lane & 31)];
+                for (int j = 0; j < TN; ++j) {
+                    const int ch = (wn * TN + j) * 32 + (lane & 31);
+                    bf[j] = *reinterpret_cast<const float *>(Ys + px * YROWB + (((ch >> 2) ^ ysw) << 4) + ((ch & 3) << 2));
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -168,8 +228,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (more) s_store(cur ^ 1);
-        __syncthreads();
     }
 
     // epilogue: rows = input channels c, cols = filters n; dW is HWIO [tap][Cin][Cout]
@@ -200,18 +258,37 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
     const int tiles = ksize * ksize * CT * NT;
     constexpr int BKP = sizeof(T) == 2 ? 32 : 16;
-    // split the pixel range so the grid has >= ~4 blocks per CU, but keep >= 8 tiles per block
-    int ks = cdiv(1024, tiles);
-    int max_ks = cdiv(M, 8 * BKP);
-    if (ks > max_ks) ks = max_ks;
+    // Pixel-range split (every block ends with one f32 atomic per output element, so fewer, longer blocks =
+    // less atomic traffic; more blocks = more latency hiding).  Measured on the Darknet-19 shapes
+    // (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
+    // blocks for the 128-wide tile / ~1024 for the 64-wide one; with fewer ranges (13x13 stages) it would
+    // leave XCDs idle, so those keep the plain mapping at ~1024 blocks.
+    static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
+    static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
+    const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
+    int target = env_target > 0 ? env_target : (BC >= 128 ? 512 : 1024);
+    int ks = cdiv(target, tiles);
+    int remap = env_remap >= 0 ? env_remap : (ks >= 8 && max_ks >= 8);
+    if (remap) {
+        ks = cdiv(ks, 8) * 8;
+        if (ks > max_ks) ks = max_ks / 8 * 8;
+        if (ks < 8) remap = 0;
+    }
+    if (!remap) {
+        if (env_target <= 0) target = 1024;
+        ks = cdiv(target, tiles);
+        if (ks > max_ks) ks = max_ks;
+    }
     if (ks < 1) ks = 1;
     int mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
     ks = cdiv(M, mchunk);
-    dim3 grid(tiles, ks);
+    if (remap && ks % 8 != 0) remap = (ks >= 8);              // rounding may have changed the count; ragged tail is fine
+    dim3 grid(remap ? tiles * (cdiv(ks, 8) * 8) : tiles * ks);
+    const unsigned x_bytes = (unsigned)((size_t)M * ldx * sizeof(T)), y_bytes = (unsigned)((size_t)M * ldy * sizeof(T));
     if (g_wgrad_variant == 0)
-        conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, (const T *)dY, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk);
+        conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
     else
-        conv_wgrad_kernel<T, BC, BNN, 1><<<grid, 256, 0, st>>>((const T *)X, (const T *)dY, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk);
+        conv_wgrad_kernel<T, BC, BNN, 1><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
 }
 
 extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin,
@@ -221,8 +298,11 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     Y2_CHECK_ARG(ksize == 1 || ksize == 3);
     Y2_CHECK_ARG(ldx >= Cin && ldy >= Cout);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    const size_t esz = dtype == YOLO2_BF16 ? 2 : 4;
     Y2_CHECK_ARG(ldx % vec == 0 && ldy % vec == 0);
-    Y2_CHECK_ARG((long)B * H * W * (long)(ldx > ldy ? ldx : ldy) < (1L << 31));
+    Y2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)dY & 15) == 0);
+    // 32-bit byte offsets below 2^31 on both operands (DMA descriptors)
+    Y2_CHECK_ARG((size_t)B * H * W * (size_t)(ldx > ldy ? ldx : ldy) * esz < (1ull << 31));
     hipStream_t st = (hipStream_t)stream;
     const bool small = Cin <= 64 || Cout <= 64;
     if (small) {

@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, in
 // FIN 0: (sum x, sum x^2) -> mean, biased var;  FIN 1: two sums -> two f32 outputs;  FIN 2: one sum -> o0
 template <int FIN>
 __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float *__restrict__ part, int nb, int C, long M,
-                                                              float *__restrict__ o0, float *__restrict__ o1, int nout) {
+                                                              float *__restrict__ o0, float *__restrict__ o1, int nout,
+                                                              float *__restrict__ mm = nullptr, float *__restrict__ mv = nullptr,
+                                                              float omd = 0.f) {
     // 16 columns x 16 row groups per block: every thread sums nb/16 partials with 4 independent f64 chains
     // (the first version walked up to 1024 partials serially per thread: 77 us of pure latency per call)
     constexpr int K = FIN == 2 ? 1 : 2;
@@ -192,8 +194,13 @@ __global__ __launch_bounds__(256) void reduce_finalize_kernel(const float *__res
             double dm = t[0] / (double)M;                       // mean of (x - shift)
             double var = t[K - 1] / (double)M - dm * dm;
             double mean = (double)part[(long)2 * nb * C + c] + dm;
-            o0[c] = (float)mean;
-            o1[c] = (float)(var > 0.0 ? var : 0.0);
+            const float fm = (float)mean, fv = (float)(var > 0.0 ? var : 0.0);
+            o0[c] = fm;
+            o1[c] = fv;
+            if (mm) {   // fused assign_moving_average (UPDATE_OPS): moving -= (1-decay)*(moving-batch)
+                mm[c] = mm[c] - (mm[c] - fm) * omd;
+                mv[c] = mv[c] - (mv[c] - fv) * omd;
+            }
         } else if (FIN == 1) {
             o0[c] = (float)t[0];
             o1[c] = (float)t[K - 1];
@@ -212,7 +219,16 @@ static int colsum_grid(long M, int C, int vec) {
     return (int)g;
 }
 
+static int bn_stats_impl(const void *Y, float *mean, float *var, float *mm, float *mv, double decay, double *ws, long M, int C, int dtype, void *stream);
 extern "C" int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws, long M, int C, int dtype, void *stream) {
+    return bn_stats_impl(Y, mean, var, nullptr, nullptr, 0.0, ws, M, C, dtype, stream);
+}
+extern "C" int yolo2_bn_stats_ema(const void *Y, float *mean, float *var, float *moving_mean, float *moving_var, double decay,
+                                  double *ws, long M, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(moving_mean && moving_var);
+    return bn_stats_impl(Y, mean, var, moving_mean, moving_var, decay, ws, M, C, dtype, stream);
+}
+static int bn_stats_impl(const void *Y, float *mean, float *var, float *mm, float *mv, double decay, double *ws, long M, int C, int dtype, void *stream) {
     Y2_CHECK_ARG(Y && mean && var && ws && M > 0 && C > 0);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256);
@@ -220,7 +236,7 @@ extern "C" int yolo2_bn_stats(const void *Y, float *mean, float *var, double *ws
     const int nb = colsum_grid(M, C, vec);
     float *part = (float *)ws;
     Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 2><<<nb, 256, 0, st>>>((const T *)Y, C, M, C, part));
-    reduce_finalize_kernel<0><<<cdiv(C, 16), 256, 0, st>>>(part, nb, C, M, mean, var, C);
+    reduce_finalize_kernel<0><<<cdiv(C, 16), 256, 0, st>>>(part, nb, C, M, mean, var, C, mm, mv, (float)(1.0 - decay));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

@@ -206,9 +206,8 @@ class Engine(object):
                     self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'])
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     if self.training:
-                        ops.bn_stats(yb, st['mean'], st['var'], self.ws, M, op['cout'])
-                        ops.bn_ema(self.var[op['moving_mean'].name], self.var[op['moving_variance'].name], st['mean'], st['var'],
-                                   op['cout'], BN_DECAY)
+                        ops.bn_stats_ema(yb, st['mean'], st['var'], self.var[op['moving_mean'].name], self.var[op['moving_variance'].name],
+                                         BN_DECAY, self.ws, M, op['cout'])
                         mean, var = st['mean'], st['var']
                     else:
                         mean, var = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]

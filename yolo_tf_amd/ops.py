@@ -37,6 +37,10 @@ def bn_stats(Y, mean, var, ws, M, C):
     call('yolo2_bn_stats', ptr(Y), ptr(mean), ptr(var), ptr(ws), M, C, dtype_code(Y.dtype), _stream())
 
 
+def bn_stats_ema(Y, mean, var, mm, mv, decay, ws, M, C):
+    call('yolo2_bn_stats_ema', ptr(Y), ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, ptr(ws), M, C, dtype_code(Y.dtype), _stream())
+
+
 def bn_ema(mm, mv, mean, var, C, decay):
     call('yolo2_bn_ema', ptr(mm), ptr(mv), ptr(mean), ptr(var), C, decay, _stream())
 
