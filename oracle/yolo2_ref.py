@@ -23,6 +23,22 @@ gradient cross-checks).
 import numpy as np
 
 # --------------------------------------------------------------------------------------
+# bf16 storage emulation (for checking the bf16 mode of the product: f32 arithmetic, values rounded to
+# bfloat16 -- round-to-nearest-even on the upper 16 bits -- wherever the product stores a bf16 tensor)
+# --------------------------------------------------------------------------------------
+
+def bf16_round(x):
+    a = np.ascontiguousarray(x, np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+def _ident(x):
+    return x
+
+
+# --------------------------------------------------------------------------------------
 # elementwise / layout ops
 # --------------------------------------------------------------------------------------
 
@@ -286,19 +302,23 @@ def trainable_names(params):
     return [k for k in params if not k.endswith(('moving_mean', 'moving_variance'))]
 
 
-def network_forward(spec, params, x, training):
+def network_forward(spec, params, x, training, quant=None):
     """Runs the op list; returns (net, caches).  Training uses batch statistics and returns
-    the moving-average updates in caches['ema'] ([TF-sem] UPDATE_OPS run by create_train_op)."""
+    the moving-average updates in caches['ema'] ([TF-sem] UPDATE_OPS run by create_train_op).
+    ``quant`` (e.g. :func:`bf16_round`) is applied wherever the product's bf16 mode stores a tensor:
+    input, filters, raw conv outputs, activations."""
+    q = quant or _ident
     caches = []
     ema = {}
-    net = x
+    net = q(x)
     mark = None
     for op in spec:
         if op[0] == 'conv':
             _, name, k, cout, bn = op
-            w = params[name + '/weights']
+            w = q(params[name + '/weights'])
             y = conv2d(net, w)
             if bn:
+                y = q(y)
                 g = params[name + '/BatchNorm/gamma']
                 bt = params[name + '/BatchNorm/beta']
                 if training:
@@ -309,10 +329,10 @@ def network_forward(spec, params, x, training):
                     mean = params[name + '/BatchNorm/moving_mean']
                     var = params[name + '/BatchNorm/moving_variance']
                 z = bn_apply(y, mean, var, g, bt)
-                out = leaky_relu(z)
+                out = q(leaky_relu(z))
                 caches.append(('conv', name, net, y, mean, var, z))
             else:
-                out = y + params[name + '/biases']
+                out = q(y + params[name + '/biases'])
                 caches.append(('conv', name, net, None, None, None, None))
             net = out
         elif op[0] == 'pool':
@@ -328,29 +348,33 @@ def network_forward(spec, params, x, training):
     return net, {'ops': caches, 'ema': ema}
 
 
-def network_backward(spec, params, caches, dnet):
-    """Reverse sweep; returns gradients for every trainable variable."""
+def network_backward(spec, params, caches, dnet, quant=None):
+    """Reverse sweep; returns gradients for every trainable variable (``quant``: see network_forward;
+    applied to every activation gradient the product stores)."""
+    q = quant or _ident
     grads = {}
     dmark = None
+    dnet = q(dnet)
     for op, cache in zip(reversed(spec), reversed(caches['ops'])):
         if op[0] == 'conv':
             _, name, k, cout, bn = op
             _, _, xin, y, mean, var, z = cache
-            w = params[name + '/weights']
+            w = q(params[name + '/weights'])
             if bn:
                 dz = leaky_relu_grad(z, dnet)
                 dy, dg, db = bn_train_bwd(y, mean, var, params[name + '/BatchNorm/gamma'], dz)
+                dy = q(dy)
                 grads[name + '/BatchNorm/gamma'] = dg
                 grads[name + '/BatchNorm/beta'] = db
             else:
                 dy = dnet
                 grads[name + '/biases'] = dy.reshape(-1, cout).astype(np.float64).sum(0).astype(dy.dtype)
             grads[name + '/weights'] = conv2d_wgrad(xin, dy, k, k)
-            dnet = conv2d_dgrad(dy, w)
+            dnet = q(conv2d_dgrad(dy, w))
         elif op[0] == 'pool':
             dnet = max_pool_grad(cache[2], dnet, cache[1])
         elif op[0] == 'mark':
-            dnet = dnet + dmark
+            dnet = q(dnet + dmark)
         elif op[0] == 'reorg_concat':
             cr = cache[1]
             dmark = reorg_grad(dnet[..., :cr])
@@ -648,15 +672,15 @@ def transform_labels(objects_class, objects_coord, classes, cell_width, cell_hei
 # --------------------------------------------------------------------------------------
 
 def train_step(spec, params, opt_state, x, labels, classes, anchors, hparam, lr, step,
-               adam=(0.9, 0.999, 1e-8)):
+               adam=(0.9, 0.999, 1e-8), quant=None):
     """Forward (batch-stat BN) + loss + backward + Adam; returns (new_params, new_state, info).
     ``step`` counts completed updates (Adam's t = step+1)."""
-    net, caches = network_forward(spec, params, x, training=True)
+    net, caches = network_forward(spec, params, x, training=True, quant=quant)
     m = model_decode(net, classes, anchors, training=True)
     obj, aux = objectives(m, labels)
     loss = total_loss(obj, hparam)
     dnet = loss_backward(m, labels, aux, hparam, classes)
-    grads = network_backward(spec, params, caches, dnet)
+    grads = network_backward(spec, params, caches, dnet, quant=quant)
     new_params = dict(params)
     new_params.update(caches['ema'])                     # UPDATE_OPS before the step [TF-sem]
     new_state = {}

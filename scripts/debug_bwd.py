@@ -11,7 +11,9 @@ from yolo_tf_amd import ops
 
 size, B, classes = int(os.environ.get('SIZE', 96)), 2, 20
 b, _ = make_builder('darknet', classes, size, True, tempfile.mkdtemp())
-sess = TrainSession(b, B, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=3)
+DT = os.environ.get('DTYPE', 'f32')
+Q = None if DT == 'f32' else R.bf16_round
+sess = TrainSession(b, B, dtype=DT, optimizer='adam', learning_rate=1e-3, seed=3)
 e = sess.engine
 scope = 'yolo2_darknet/'
 params = {k[len(scope):]: v for k, v in e.get_variables().items()}
@@ -29,11 +31,12 @@ torch.cuda.synchronize()
 
 spec = R.darknet_spec(classes, 5)
 x = np.stack([R.per_image_standardization(i) for i in images]).astype(np.float32)
-net, caches = R.network_forward(spec, params, x, True)
+net, caches = R.network_forward(spec, params, x, True, quant=Q)
 m = R.model_decode(net, classes, b.anchors, True)
 hp = {'prob': 1., 'iou_best': 5., 'iou_normal': 1., 'coords': 1.}
 obj, aux = R.objectives(m, labels)
 dnet = R.loss_backward(m, labels, aux, hp, classes)
+if Q: dnet = Q(dnet)
 
 def rel(a, r): return float(np.abs(a - r).max() / (np.abs(r).max() + 1e-30))
 def gpu_act(t, grad=False):
@@ -58,10 +61,11 @@ for op, cache in zip(reversed(spec), reversed(caches['ops'])):
         flat = buf.float().cpu().numpy()
         d_out_g = np.stack([flat[i * ld:i * ld + t.c] for i in range(n)]).reshape(B, t.h, t.w, t.c)
         r_dout = rel(d_out_g, dnet)
-        w = params[name + '/weights']
+        w = params[name + '/weights'] if not Q else Q(params[name + '/weights'])
         if bn:
             dz = R.leaky_relu_grad(z, dnet)
             dy, dg, db = R.bn_train_bwd(y, mean, var, params[name + '/BatchNorm/gamma'], dz)
+            if Q: dy = Q(dy)
             r_dg, r_db = rel(grads_gpu[name + '/BatchNorm/gamma'], dg), rel(grads_gpu[name + '/BatchNorm/beta'], db)
             st = e.conv[gop['name']]
             ry = rel(gpu_act(gop['y']), y); rm = rel(st['mean'].cpu().numpy(), mean); rv = rel(st['var'].cpu().numpy(), var)
@@ -70,6 +74,7 @@ for op, cache in zip(reversed(spec), reversed(caches['ops'])):
         dW = R.conv2d_wgrad(xin, dy, k, k)
         r_dw = rel(grads_gpu[name + '/weights'], dW)
         dnet = R.conv2d_dgrad(dy, w)
+        if Q: dnet = Q(dnet)
         r_din = float('nan')
         if gop['x'] in e.gact and name != 'conv13':
             tx = gop['x']; bufx, ldx = e.gact[tx]; nx = B * tx.h * tx.w; fx = bufx.float().cpu().numpy()
@@ -79,7 +84,7 @@ for op, cache in zip(reversed(spec), reversed(caches['ops'])):
     elif op[0] == 'pool':
         dnet = R.max_pool_grad(cache[2], dnet, cache[1])
     elif op[0] == 'mark':
-        dnet = dnet + dmark
+        dnet = dnet + dmark if not Q else Q(dnet + dmark)
     elif op[0] == 'reorg_concat':
         cr = cache[1]
         dmark = R.reorg_grad(dnet[..., :cr]); dnet = dnet[..., cr:]
