@@ -72,6 +72,18 @@ int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW,
 int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin, int ldcin,
                       int Cout, int ldcout, int dtype, void *stream);
 
+/* The same for every layer of a network in one launch.  `descs_device` is a DEVICE array of n descriptors
+ * sorted by first_block; layer i owns blocks [first_block_i, first_block_{i+1}) and needs
+ * ksize^2 * ceil(ldcin/32) * ceil(ldcout/32) of them; total_blocks = end of the last layer. */
+typedef struct yolo2_filter_desc {
+    const float *W;      /* HWIO f32 master weights */
+    void *Ffwd;          /* [Cout][k*k*ldcin]  or NULL */
+    void *Fdgr;          /* [Cin ][k*k*ldcout] or NULL */
+    int ksize, cin, ldcin, cout, ldcout, first_block;
+} yolo2_filter_desc;
+int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype,
+                            void *stream);
+
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
 /* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1025*C doubles of scratch

@@ -70,7 +70,9 @@ def run_conv(ops, x, w, bias, tdtype, ldo=None):
 CONV_SHAPES = [
     # B, H, W, Cin, Cout, k
     (2, 13, 13, 16, 40, 3),
-    (1, 26, 20, 3, 32, 3),      # conv0-like: 3 real channels in an 8-wide pixel stride, Cout tile 32
+    (1, 26, 20, 3, 32, 3),      # conv0-like: 3 real channels in an 8-wide pixel stride -> first-layer direct kernels
+    (2, 33, 70, 3, 32, 3),      # first layer, ragged 32-pixel segments
+    (1, 64, 96, 3, 32, 3),      # first layer, exact segments
     (2, 13, 13, 64, 125, 1),    # final 1x1 + bias, ragged Cout, padded ldo
     (2, 26, 26, 64, 160, 3),    # two N tiles, M tail (1352 rows)
     (1, 8, 8, 24, 64, 3),       # BN=64 tile, channel tail inside a K step
@@ -189,6 +191,32 @@ def test_filter_prep_exact(ops):
     ed[:, :, :Cout] = w[::-1, ::-1].reshape(9, Cin, Cout).transpose(1, 0, 2)
     assert np.array_equal(host(Ff).reshape(Cout, 9, ldcin), ef)
     assert np.array_equal(host(Fd).reshape(Cin, 9, ldcout), ed)
+
+
+def test_filter_prep_batch_matches_per_layer(ops):
+    import ctypes
+    from yolo_tf_amd._lib import FilterDesc
+    rng = np.random.RandomState(1)
+    layers = [(3, 3, 32), (3, 32, 64), (1, 128, 64), (3, 40, 125), (1, 1024, 125)]
+    for tdtype in (torch.float32, torch.bfloat16):
+        arr = (FilterDesc * len(layers))()
+        keep, first = [], 0
+        for d, (k, cin, cout) in zip(arr, layers):
+            ldcin, ldcout = ops.pad8(cin), ops.pad8(cout)
+            w = dev(rng.randn(k, k, cin, cout).astype(np.float32))
+            ff = torch.full((cout * k * k * ldcin,), 3.0, dtype=tdtype, device='cuda')
+            fd = torch.full((cin * k * k * ldcout,), 3.0, dtype=tdtype, device='cuda')
+            ef, ed = torch.zeros_like(ff), torch.zeros_like(fd)
+            ops.filter_prep(w, ef, ed, k, cin, ldcin, cout, ldcout, tdtype)
+            d.W, d.Ffwd, d.Fdgr = w.data_ptr(), ff.data_ptr(), fd.data_ptr()
+            d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, cin, ldcin, cout, ldcout, first
+            first += k * k * ((ldcin + 31) // 32) * ((ldcout + 31) // 32)
+            keep.append((w, ff, fd, ef, ed))
+        descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        ops.filter_prep_batch(descs, len(layers), first, tdtype)
+        torch.cuda.synchronize()
+        for w, ff, fd, ef, ed in keep:
+            assert torch.equal(ff, ef) and torch.equal(fd, ed)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])

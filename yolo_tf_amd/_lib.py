@@ -29,6 +29,7 @@ SIGNATURES = {
     'yolo2_conv2d_ws': [_p, _p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_conv2d_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_filter_prep_batch': [_p, _i, _i, _i, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],
     'yolo2_bn_stats_ema': [_p, _p, _p, _p, _p, ctypes.c_double, _p, _l, _i, _i, _p],
     'yolo2_bn_ema': [_p, _p, _p, _p, _i, ctypes.c_double, _p],
@@ -55,6 +56,12 @@ SIGNATURES = {
     'yolo2_clip_by_norm': [_p, _p, _i, _f, _p, _p],
     'yolo2_selftest_tr16': [_p, _p],
 }
+
+class FilterDesc(ctypes.Structure):
+    """yolo2_filter_desc of include/yolo2_hip.h"""
+    _fields_ = [('W', ctypes.c_void_p), ('Ffwd', ctypes.c_void_p), ('Fdgr', ctypes.c_void_p), ('ksize', _i), ('cin', _i),
+                ('ldcin', _i), ('cout', _i), ('ldcout', _i), ('first_block', _i)]
+
 
 _lib = None
 

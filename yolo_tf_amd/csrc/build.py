@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     'conv_igemm.hip': [],
     'conv_wgrad.hip': [],
+    'conv_first.hip': [],
     'elementwise.hip': [],
     'head.hip': ['-ffp-contract=off'],
     'nms.hip': ['-ffp-contract=off'],

@@ -1,0 +1,288 @@
+// Direct 3x3 convolution for the FIRST layer (image input: 3 channels in an 8-wide pixel stride,
+// 32 filters): forward and filter gradient, gfx950.
+//
+// conv0 is 0.9 % of the network's MACs but 5.5 M output pixels per image: it is HBM-bound (write 177 MB of
+// outputs / read them back as dY at batch 16), and the generic implicit-GEMM kernels waste it -- the forward
+// pads every tap's 8 channels to a 32-wide K step, the filter gradient re-reads dY once per tap (9x).
+// Here one WAVE owns one segment of 32 consecutive output pixels of an image row:
+//   * the 3 x 34-pixel input halo (16 B per pixel) and, for the gradient, the 32 x 32 dY block are DMA-ed
+//     into a wave-private LDS slot (buffer_load ... lds; out-of-image rows / pixels and segment tails are
+//     out-of-range offsets -> zeros), double buffered, no workgroup barrier in the loop;
+//   * forward: all 9 taps x 8 channels form ONE reduction of length 72 (padded to 80 = 5 bf16 MFMA steps):
+//     the A fragment of step s for pixel i is simply the 16 contiguous bytes of halo pixel (i + dw) in halo
+//     row dh of tap 2s + (lane>>5); the filters (32 x 80) live in registers;
+//   * filter gradient: rows = (tap, channel) = 72 (3 MFMA row tiles), cols = 32 filters, reduction = the
+//     segment's 32 pixels; fragments by ds_read_b64_tr_b16 with per-lane tap-shifted addresses; each wave
+//     keeps 3 accumulator tiles over all its segments, waves are combined through LDS and written with one
+//     f32 atomic per output element per workgroup.
+#include "common.h"
+#include <type_traits>
+
+#define Y2_OOB 0x80000000u
+
+// ---------------------------------------------------------------------------------------------------
+// shared staging: halo rows h-1, h, h+1, pixels w0-1 .. w0+32 of image b, 8 channels per pixel
+// ---------------------------------------------------------------------------------------------------
+template <typename T> struct First {
+    static constexpr int PXB = 8 * sizeof(T);              // bytes per halo pixel (16 bf16 / 32 f32)
+    static constexpr int HPIECES = PXB / 16;               // DMA pieces per halo row (64 lanes x 16 B = 1 KiB)
+    static constexpr int HROWB = HPIECES * 1024;           // LDS bytes reserved per halo row
+    static constexpr int HALO = 3 * HROWB;
+};
+
+template <typename T>
+__device__ __forceinline__ void stage_halo(const __amdgpu_buffer_rsrc_t &rsrcX, unsigned char *dst, int b, int h, int w0, int H, int W, int lane) {
+    constexpr int PXB = First<T>::PXB, HP = First<T>::HPIECES;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int hh = h + r - 1;
+#pragma unroll
+        for (int p = 0; p < HP; ++p) {
+            const int chunk = p * 64 + lane;                   // 16-byte chunk index inside the halo row
+            const int px = chunk / HP;                         // halo pixel 0..33 (beyond: unused)
+            const int ww = w0 - 1 + px;
+            const bool ok = px < 34 && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+            const unsigned voff = ok ? (unsigned)((((long)b * H + hh) * W + ww) * PXB + (chunk % HP) * 16) : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(dst + r * First<T>::HROWB + p * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ F, T *__restrict__ Y,
+                                                             int B, int H, int W, int units) {
+    constexpr int SLOT = First<T>::HALO, PXB = First<T>::PXB;
+    constexpr int LOADS = 3 * First<T>::HPIECES;
+    constexpr int KS = sizeof(T) == 2 ? 5 : 36;              // MFMA steps over the 72 (80) reduction values
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * 2 * SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *my = smem + wave * 2 * SLOT;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), 0, x_bytes, 0x00020000);
+    const int SW = (W + 31) / 32;
+
+    // filters of column n = lane&31 in registers: F is [32][72] (K-contiguous), zero beyond 72
+    typename std::conditional<sizeof(T) == 2, bf16x8, float>::type bf[KS];
+    const int n = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = s * 16 + half * 8 + e;
+                bf[s][e] = k < 72 ? F[n * 72 + k] : (bf16)0.f;
+            }
+        } else {
+            const int k = s * 2 + half;
+            bf[s] = F[n * 72 + k];
+        }
+    }
+
+    const int stride = gridDim.x * 4;
+    int u = blockIdx.x * 4 + wave;
+    if (u >= units) return;
+    auto decode = [&](int uu, int &b, int &h, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h = t % H; b = t / H; };
+    int b, h, w0;
+    decode(u, b, h, w0);
+    stage_halo<T>(rsrcX, my, b, h, w0, H, W, lane);
+    int st = 0;
+    for (; u < units; u += stride) {
+        const int un = u + stride;
+        int nb = 0, nh = 0, nw0 = 0;
+        if (un < units) {
+            decode(un, nb, nh, nw0);
+            stage_halo<T>(rsrcX, my + (st ^ 1) * SLOT, nb, nh, nw0, H, W, lane);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");   // everything older than the just-issued DMA has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char *hs = my + st * SLOT;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int i = lane & 31;                              // output pixel of this lane's A row
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (sizeof(T) == 2) {
+                int tap = 2 * s + half;
+                if (tap > 8) tap = 8;                         // padding step: filters are zero there, data must merely be finite
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(hs + (tap / 3) * First<T>::HROWB + (i + tap % 3) * PXB);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc, 0, 0, 0);
+            } else {
+                const int k = 2 * s + half, tap = k >> 3, c = k & 7;
+                const float a = *reinterpret_cast<const float *>(hs + (tap / 3) * First<T>::HROWB + (i + tap % 3) * PXB + c * 4);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s], acc, 0, 0, 0);
+            }
+        }
+        // D: col = lane&31 = filter, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = pixel of the segment
+        T *out = Y + (((long)b * H + h) * W + w0) * 32 + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (w0 + px < W) out[(long)px * 32] = (T)acc[r];
+        }
+        b = nb; h = nh; w0 = nw0;
+        st ^= 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// filter gradient
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes,
+                                                               float *__restrict__ dW, int B, int H, int W, int Cin, int units) {
+    constexpr int PXB = First<T>::PXB, HALO = First<T>::HALO;
+    constexpr int YROWB = 32 * sizeof(T);                    // dY bytes per pixel (64 / 128)
+    constexpr int YPIECES = 32 * YROWB / 1024;               // 2 / 4
+    constexpr int SLOT = HALO + YPIECES * 1024;
+    constexpr int LOADS = 3 * First<T>::HPIECES + YPIECES;
+    constexpr int RED = 4 * 3 * 16 * 64 * 4;                 // cross-wave reduction scratch (reuses the staging area)
+    constexpr int SMEM = 4 * 2 * SLOT > RED ? 4 * 2 * SLOT : RED;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *my = smem + wave * 2 * SLOT;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dY), 0, y_bytes, 0x00020000);
+    const int SW = (W + 31) / 32;
+
+    auto stage = [&](unsigned char *dst, int b, int h, int w0) {
+        stage_halo<T>(rsrcX, dst, b, h, w0, H, W, lane);
+#pragma unroll
+        for (int p = 0; p < YPIECES; ++p) {
+            const int chunk = p * 64 + lane;
+            const int px = chunk / (YROWB / 16);
+            const bool ok = w0 + px < W;
+            const unsigned voff = ok ? (unsigned)((((long)b * H + h) * W + w0 + px) * YROWB + (chunk % (YROWB / 16)) * 16) : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void *)(dst + HALO + p * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int stride = gridDim.x * 4;
+    int u = blockIdx.x * 4 + wave;
+    auto decode = [&](int uu, int &b, int &h, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h = t % H; b = t / H; };
+    if (u < units) {
+        int b, h, w0;
+        decode(u, b, h, w0);
+        stage(my, b, h, w0);
+    }
+    const int g = lane >> 4, t16 = lane & 15;
+    int st = 0;
+    for (; u < units; u += stride) {
+        const int un = u + stride;
+        if (un < units) {
+            int nb, nh, nw0;
+            decode(un, nb, nh, nw0);
+            stage(my + (st ^ 1) * SLOT, nb, nh, nw0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char *hs = my + st * SLOT;
+        const unsigned char *ys = hs + HALO;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfrag, afrag[3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t16 >> 2);     // pixel row this lane addresses
+                    {
+                        const unsigned char *p = ys + px * YROWB + (16 * (g & 1) + 4 * (t16 & 3)) * 2;
+                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+                        bf16x4 q = __builtin_bit_cast(bf16x4, v);
+                        bfrag[4 * r] = q[0]; bfrag[4 * r + 1] = q[1]; bfrag[4 * r + 2] = q[2]; bfrag[4 * r + 3] = q[3];
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) {
+                        const int row = 32 * rt + 16 * (g & 1) + 4 * (t16 & 3);       // first of the 4 (tap, channel) rows this lane addresses
+                        int tap = row >> 3;
+                        if (tap > 8) tap = 8;                                          // rows 72..95: discarded at the end
+                        const unsigned char *p = hs + (tap / 3) * First<T>::HROWB + (px + tap % 3) * PXB + (row & 7) * 2;
+                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+                        bf16x4 q = __builtin_bit_cast(bf16x4, v);
+                        afrag[rt][4 * r] = q[0]; afrag[rt][4 * r + 1] = q[1]; afrag[rt][4 * r + 2] = q[2]; afrag[rt][4 * r + 3] = q[3];
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rt], bfrag, acc[rt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int px = ks * 2 + (lane >> 5);
+                const float bv = *reinterpret_cast<const float *>(ys + px * YROWB + (lane & 31) * 4);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    const int row = 32 * rt + (lane & 31);
+                    int tap = row >> 3;
+                    if (tap > 8) tap = 8;
+                    const float av = *reinterpret_cast<const float *>(hs + (tap / 3) * First<T>::HROWB + (px + tap % 3) * PXB + (row & 7) * 4);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        st ^= 1;
+    }
+
+    // combine the 4 waves through LDS (the staging slots are dead now), then one atomic per element per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);            // [4 waves][3 tiles][16 regs][64 lanes] = 48 KiB
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + rt) * 16 + r) * 64 + lane] = acc[rt][r];
+    __syncthreads();
+    if (wave == 0) {
+        const int n = lane & 31;
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);    // (tap, channel)
+                const int tap = row >> 3, c = row & 7;
+                if (tap < 9 && c < Cin) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[((w * 3 + rt) * 16 + r) * 64 + lane];
+                    unsafeAtomicAdd(dW + ((long)tap * Cin + c) * 32 + n, v);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host entry points used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches
+// ---------------------------------------------------------------------------------------------------
+bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize) { return ksize == 3 && Cp == 8 && ldp == 8 && Nf == 32 && ldo == 32; }
+
+int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st) {
+    const int units = B * H * ((W + 31) / 32);
+    const int grid = units / 4 + 1 < 2048 ? units / 4 + 1 : 2048;
+    // the forward filter operand is [32][9*8]: the generic layout with ldcin = 8
+    if (dtype == YOLO2_BF16)
+        conv_first_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)O, B, H, W, units);
+    else
+        conv_first_fwd_kernel<float><<<grid, 256, 0, st>>>((const float *)P, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)F, (float *)O, B, H, W, units);
+    return 0;
+}
+
+int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int dtype, hipStream_t st) {
+    const int units = B * H * ((W + 31) / 32);
+    const int grid = units / 4 + 1 < 512 ? units / 4 + 1 : 512;
+    if (dtype == YOLO2_BF16)
+        conv_first_wgrad_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)X, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)dY, (unsigned)((size_t)B * H * W * 32 * 2), dW, B, H, W, Cin, units);
+    else
+        conv_first_wgrad_kernel<float><<<grid, 256, 0, st>>>((const float *)X, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)dY, (unsigned)((size_t)B * H * W * 32 * 4), dW, B, H, W, Cin, units);
+    return 0;
+}

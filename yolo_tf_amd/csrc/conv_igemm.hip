@@ -249,7 +249,7 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
 struct Tune { int target_blocks; int stages; int remap; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{0, 3, -1};     // K slicing off: with the lean DMA loop it no longer pays on any Darknet-19 layer (profiles/)
+        Tune v{352, 3, -1};   // K slicing only for grids below half the chip (see choose_ksplit)
         if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_STAGES")) v.stages = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
@@ -260,7 +260,7 @@ static const Tune &tune() {   // tuning knobs (defaults = measured best); env ov
 // number of K slices: when the M x N tile grid alone cannot fill 256 CUs with ~2-3 resident workgroups
 // each, slice K so that it does, keeping >= 8 K tiles per slice
 static int choose_ksplit(int tiles, int nk, int target) {
-    if (target <= 0 || tiles * 3 >= target * 2 || nk < 32) return 1;
+    if (target <= 0 || tiles > 128 || nk < 32) return 1;   // measured: pays only for the 88-tile data gradients
     int ks = (target + tiles - 1) / tiles;
     int max_ks = nk / 8;
     if (ks > max_ks) ks = max_ks;
@@ -340,6 +340,13 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         return YOLO2_E_ARG;
     }
     int rc = 0;
+    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    if (first_direct && !bias && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
+        if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
+        y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream);
+        Y2_CHECK_LAUNCH();
+        return YOLO2_OK;
+    }
     Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream));
     if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
     Y2_CHECK_LAUNCH();

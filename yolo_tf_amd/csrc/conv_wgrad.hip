@@ -304,6 +304,12 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     // 32-bit byte offsets below 2^31 on both operands (DMA descriptors)
     Y2_CHECK_ARG((size_t)B * H * W * (size_t)(ldx > ldy ? ldx : ldy) * esz < (1ull << 31));
     hipStream_t st = (hipStream_t)stream;
+    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize) && (dtype == YOLO2_F32 || dtype == YOLO2_BF16)) {
+        y2_first_layer_wgrad(X, dY, dW, B, H, W, Cin, dtype, st);                       // image layer: direct kernel (conv_first.hip)
+        Y2_CHECK_LAUNCH();
+        return YOLO2_OK;
+    }
     const bool small = Cin <= 64 || Cout <= 64;
     if (small) {
         Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 64, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));

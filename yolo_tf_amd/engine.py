@@ -172,14 +172,27 @@ class Engine(object):
             t.stop()
 
     def _prepare_filters(self):
+        """HWIO f32 masters -> both MFMA operand layouts of every layer, one launch (descriptor table built once)."""
         if not self._filters_dirty:
             return
-        for op in self.graph.ops:
-            if op['kind'] != 'conv':
-                continue
-            st = self.conv[op['name']]
-            ops.filter_prep(self.var[op['weights'].name], st['Ffwd'], st.get('Fdgr'), op['ksize'], op['cin'], pad8(op['cin']),
-                            op['cout'], pad8(op['cout']), self.dtype)
+        if getattr(self, '_fdesc', None) is None:
+            import ctypes
+            from ._lib import FilterDesc
+            convs = [op for op in self.graph.ops if op['kind'] == 'conv']
+            arr = (FilterDesc * len(convs))()
+            first = 0
+            for d, op in zip(arr, convs):
+                st = self.conv[op['name']]
+                k, ldcin, ldcout = op['ksize'], pad8(op['cin']), pad8(op['cout'])
+                d.W = self.var[op['weights'].name].data_ptr()
+                d.Ffwd = st['Ffwd'].data_ptr()
+                d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
+                d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
+                first += k * k * ((ldcin + 31) // 32) * ((ldcout + 31) // 32)
+            raw = bytes(arr)
+            self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._fdesc_n, self._fdesc_blocks = len(convs), first
+        ops.filter_prep_batch(self._fdesc, self._fdesc_n, self._fdesc_blocks, self.dtype)
         self._filters_dirty = False
 
     def set_images(self, images, mode=0):

@@ -33,6 +33,10 @@ def filter_prep(Wt, Ffwd, Fdgr, ksize, Cin, ldcin, Cout, ldcout, dtype):
     call('yolo2_filter_prep', ptr(Wt), ptr(Ffwd), ptr(Fdgr), ksize, Cin, ldcin, Cout, ldcout, dtype_code(dtype), _stream())
 
 
+def filter_prep_batch(descs_dev, n, total_blocks, dtype):
+    call('yolo2_filter_prep_batch', ptr(descs_dev), n, total_blocks, dtype_code(dtype), _stream())
+
+
 def bn_stats(Y, mean, var, ws, M, C):
     call('yolo2_bn_stats', ptr(Y), ptr(mean), ptr(var), ptr(ws), M, C, dtype_code(Y.dtype), _stream())
 
