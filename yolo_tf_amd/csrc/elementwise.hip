@@ -188,7 +188,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, in
 #pragma unroll
         for (int j = 0; j < N; ++j) acc[k][j] = 0.f;
     if (rm.active) {
-        for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
+        const long step = (long)gridDim.x * rm.rpp;
+        long r = (long)blockIdx.x * rm.rpp + rm.rs;
+        for (; r + 3 * step < M; r += 4 * step) {          // 4 independent 16-byte loads in flight per lane
+            Vec16<T> v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld16(X + (r + u * step) * ld + rm.cg * N);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float x = v[u].get(j) - sh[j];
+                    acc[0][j] += x;
+                    if (K == 2) acc[K - 1][j] += x * x;
+                }
+        }
+        for (; r < M; r += step) {
             Vec16<T> v = ld16(X + r * ld + rm.cg * N);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -386,8 +401,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
         bt[j] = ok ? beta[c] : 0.f;
     }
     if (rm.active) {
-        for (long r = (long)blockIdx.x * rm.rpp + rm.rs; r < M; r += (long)gridDim.x * rm.rpp) {
-            Vec16<T> y = ld16(Y + r * C + rm.cg * N), d = ld16(dA + r * ldda + rm.cg * N);
+        const long step = (long)gridDim.x * rm.rpp;
+        long r = (long)blockIdx.x * rm.rpp + rm.rs;
+        auto accum = [&](const Vec16<T> &y, const Vec16<T> &d) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float xh = (y.get(j) - mu[j]) * inv[j];
@@ -396,6 +412,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
                 part[0][j] += g * xh;  // dgamma
                 part[1][j] += g;       // dbeta
             }
+        };
+        for (; r + step < M; r += 2 * step) {              // 4 independent 16-byte loads in flight per lane
+            Vec16<T> y0 = ld16(Y + r * C + rm.cg * N), d0 = ld16(dA + r * ldda + rm.cg * N);
+            Vec16<T> y1 = ld16(Y + (r + step) * C + rm.cg * N), d1 = ld16(dA + (r + step) * ldda + rm.cg * N);
+            accum(y0, d0);
+            accum(y1, d1);
+        }
+        for (; r < M; r += step) {
+            Vec16<T> y = ld16(Y + r * C + rm.cg * N), d = ld16(dA + r * ldda + rm.cg * N);
+            accum(y, d);
         }
     }
     block_colsum_store<N, 2>(part, rm, C, ws, gridDim.x);
