@@ -126,7 +126,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--detect', action='store_true', help='also report batch-256 detect p50/p99 (config #5) on rank 0')
+    ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
     args = ap.parse_args()
 
     from yolo_tf_amd.parallel import init_distributed
@@ -197,7 +197,9 @@ def main():
                                'share_of_step_time': ks['total_ms'] / (elapsed * 1e3)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.names, args.size)
-        if args.detect and world == 1:
+        if world == 1 and not args.no_detect:
+            del sess
+            torch.cuda.empty_cache()
             out['detect'] = detect_latency(args, basedir)
         print(json.dumps(out), flush=True)
     barrier()

@@ -336,7 +336,8 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     const size_t esz = dtype == YOLO2_BF16 ? 2 : 4;
     // the DMA path addresses both operands with 32-bit byte offsets below 2^31
-    if ((size_t)B * H * W * (size_t)(ldp > ldo ? ldp : ldo) * esz >= (1ull << 31) || (size_t)Nf * ksize * ksize * Cp * esz >= (1ull << 31) ||
+    // (only the two DMA-read operands; the output is addressed with 64-bit pointers)
+    if ((size_t)B * H * W * (size_t)ldp * esz >= (1ull << 31) || (size_t)Nf * ksize * ksize * Cp * esz >= (1ull << 31) || (size_t)B * H * W >= (1ull << 31) ||
         Cp % vec || ldp % vec || ((uintptr_t)P & 15) || ((uintptr_t)F & 15)) {
         yolo2_set_error("%s: argument check failed: operand >= 2 GiB or misaligned (channels must be a multiple of %d)", fn, vec);
         return YOLO2_E_ARG;
