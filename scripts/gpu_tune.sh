@@ -1,10 +1,16 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-make -C oracle >/dev/null 2>&1
-timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -2
 {
-for cfg in "1024 0" "1024 1" "512 1" "256 1" "2048 1"; do set -- $cfg
-YOLO2_WGRAD_BLOCKS=$1 YOLO2_WGRAD_REMAP=$2 python scripts/conv_bench.py "wgrad blocks$1 remap$2"
-done
+for d in 0 1 2 3 4; do YOLO2_KSPLIT_BLOCKS=0 YOLO2_IGEMM_DBG=$d python scripts/conv_bench.py "dbg$d"; done
 } > gpurun_out/conv_bench.log 2>&1
-grep "totals" gpurun_out/conv_bench.log
+python - <<'PY'
+txt=open('gpurun_out/conv_bench.log').read().split('\n')
+runs={}; cur=None
+for l in txt:
+    if l.startswith('layer'): cur=l.split(')')[-1].strip(); runs[cur]={}
+    elif l.startswith('conv') and cur: runs[cur][l.split()[0]]=l[8:].split()
+names=list(runs)
+print('fwd us:  %-8s'%'layer', ' '.join('%10s'%n for n in names))
+for layer in runs[names[0]]:
+    print('         %-8s'%layer, ' '.join('%10s'%runs[n][layer][0].split('|')[0] for n in names))
+PY

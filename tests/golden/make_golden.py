@@ -11,6 +11,7 @@ Reference functions exercised:
     utils/data/__init__.py:112-145  transform_labels
     model/yolo/__init__.py:29-34    calc_cell_xy
     utils/preprocess.py:23-25       per_image_standardization
+    parse_darknet_yolo2.py:34-48    transpose_weights, transpose_biases
     model/yolo2/function.py:32-47   reorg known-answer image (the TF op itself cannot run; the
                                     KAT's input and its asserted per-channel constants are stored)
 """
@@ -172,6 +173,27 @@ def make_labels(data_mod, yolo_mod, pre_mod):
     print('labels.npz', len(cases), 'arrays')
 
 
+def make_weights():
+    """parse_darknet_yolo2.py:34-48 transpose_weights / transpose_biases (final-layer channel permutation)."""
+    for n in ('pandas',):
+        try:
+            __import__(n)
+        except ImportError:
+            sys.modules[n] = types.ModuleType(n)
+    ref = _load('parse_darknet_yolo2.py', 'ref_parse_darknet')
+    rng = np.random.RandomState(21)
+    cases = {}
+    for name, anchors, classes, cin in (('voc', 5, 20, 7), ('coco', 5, 80, 3), ('a3c4', 3, 4, 2)):
+        w = rng.randn(1, 1, cin, anchors * (5 + classes)).astype(np.float32)
+        b = rng.randn(anchors * (5 + classes)).astype(np.float32)
+        cases[name + '/anchors'] = np.int64(anchors)
+        cases[name + '/w_in'], cases[name + '/b_in'] = w, b
+        cases[name + '/w_out'] = ref.transpose_weights(w, anchors)
+        cases[name + '/b_out'] = ref.transpose_biases(b, anchors)
+    np.savez_compressed(os.path.join(OUT, 'weights.npz'), **cases)
+    print('weights.npz', len(cases), 'arrays')
+
+
 def main():
     _stub_tf()
     sys.path.insert(0, REF)
@@ -181,6 +203,7 @@ def main():
     import model.yolo as ref_yolo          # noqa: E402
     make_nms(post)
     make_labels(ref_data, ref_yolo, pre)
+    make_weights()
 
 
 if __name__ == '__main__':

@@ -50,7 +50,8 @@ template <> struct Mma<float> {
 
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
-template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL>
+// DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
+template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     constexpr int A_IT = BM / RPI / 4;     // DMA instructions per wave per tile
     constexpr int B_PIECES = BN / RPI;
     constexpr int B_IT = (B_PIECES + 3) / 4;
-    constexpr int LOADS = A_IT + B_IT;     // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
+    constexpr int LOADS = ((DBG & 1) ? 0 : A_IT) + ((DBG & 2) ? 0 : B_IT);   // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
     constexpr int PAD = KS / 2;
     constexpr int STAGE = (BM + B_IT * 4 * RPI) * ROWB;
     static_assert(NSTAGE >= 2 && NSTAGE <= 4 && TM >= 1 && TN >= 1, "tile");
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         unsigned char *As = smem + i_stage * STAGE;
         unsigned char *Bs = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) {
+        for (int i = 0; i < ((DBG & 1) ? 0 : A_IT); ++i) {
             bool ok = (a_mask[i] & tapbit) != 0;
             if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
             const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) {
+        for (int i = 0; i < ((DBG & 2) ? 0 : B_IT); ++i) {
             unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
             if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
@@ -210,7 +211,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) {
+                    if (DBG == 4) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); } else acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+                }
         }
     }
 
@@ -313,6 +316,16 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
+            static const int dbg = getenv("YOLO2_IGEMM_DBG") ? atoi(getenv("YOLO2_IGEMM_DBG")) : 0;
+            if constexpr (sizeof(T) == 2) {
+                if (dbg && ksize == 3 && !ctail) {
+                    if (dbg == 1) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 1><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
+                    else if (dbg == 2) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 2><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
+                    else if (dbg == 3) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 3><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
+                    else conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 4><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
+                    return 0;
+                }
+            }
             if (tu.stages == 4) Y2_IGEMM_KS_CT(128, 2, 4, false, grid);
             else if (tu.stages == 2) Y2_IGEMM_KS_CT(128, 2, 2, false, grid);
             else Y2_IGEMM_KS_CT(128, 2, 3, false, grid);
