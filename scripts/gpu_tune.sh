@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 {
-for d in 0 1 2 3 4; do YOLO2_KSPLIT_BLOCKS=0 YOLO2_IGEMM_DBG=$d python scripts/conv_bench.py "dbg$d"; done
+for d in 0 9 10 11; do YOLO2_KSPLIT_BLOCKS=0 YOLO2_IGEMM_DBG=$d python scripts/conv_bench.py "dbg$d"; done
 } > gpurun_out/conv_bench.log 2>&1
 python - <<'PY'
 txt=open('gpurun_out/conv_bench.log').read().split('\n')

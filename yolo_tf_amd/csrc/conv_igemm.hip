@@ -51,25 +51,26 @@ template <> struct Mma<float> {
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
 // DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
-template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL, int DBG = 0>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(
+template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
     constexpr int BM = 128;
-    constexpr int CH = 4;                  // 16-byte chunks per tile row
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int BK = CH * VEC;           // 32 bf16 / 16 f32
-    constexpr int ROWB = CH * 16;          // 64 bytes per tile row
+    constexpr int BK = CH * VEC;           // CH = 16-byte chunks per tile row: 4 -> 32 bf16 / 16 f32 per K step
+    constexpr int ROWB = CH * 16;          // bytes per tile row
     constexpr int RPL = 256 / ROWB;        // rows per 256-byte LDS bank line
     constexpr int RPI = 64 / CH;           // rows per DMA instruction (1 KiB)
-    constexpr int WGM = 4 / WGN;
+    constexpr int WGM = NW / WGN;          // NW waves per workgroup, arranged WGM x WGN over the output tile
     constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
-    constexpr int A_IT = BM / RPI / 4;     // DMA instructions per wave per tile
+    constexpr int A_IT = BM / RPI / NW;    // DMA instructions per wave per tile
     constexpr int B_PIECES = BN / RPI;
-    constexpr int B_IT = (B_PIECES + 3) / 4;
-    constexpr int LOADS = ((DBG & 1) ? 0 : A_IT) + ((DBG & 2) ? 0 : B_IT);   // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
+    constexpr int B_IT = (B_PIECES + NW - 1) / NW;
+    constexpr bool NOA = (DBG == 1 || DBG == 3 || DBG >= 5), NOB = (DBG == 2 || DBG == 3 || DBG >= 5);
+    constexpr int LOADS = (NOA ? 0 : A_IT) + (NOB ? 0 : B_IT);   // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
     constexpr int PAD = KS / 2;
-    constexpr int STAGE = (BM + B_IT * 4 * RPI) * ROWB;
+    constexpr int STAGE = (BM + B_IT * NW * RPI) * ROWB;
+    static_assert(A_IT >= 1, "at least one A piece per wave");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4 && TM >= 1 && TN >= 1, "tile");
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
@@ -153,14 +154,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         unsigned char *As = smem + i_stage * STAGE;
         unsigned char *Bs = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < ((DBG & 1) ? 0 : A_IT); ++i) {
+        for (int i = 0; i < (NOA ? 0 : A_IT); ++i) {
             bool ok = (a_mask[i] & tapbit) != 0;
             if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
             const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < ((DBG & 2) ? 0 : B_IT); ++i) {
+        for (int i = 0; i < (NOB ? 0 : B_IT); ++i) {
             unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
             if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // tile kt complete in LDS for every wave; tile kt-1's buffer is free
+        if (DBG != 5 && DBG != 7) __builtin_amdgcn_s_barrier();      // tile kt complete in LDS for every wave; tile kt-1's buffer is free
         if (kt_issue < kt_end) issue_next();
         const unsigned char *As = smem + c_stage * STAGE + (wm * TM * 32 + frow) * ROWB;
         const unsigned char *Bs = smem + c_stage * STAGE + (BM + wn * TN * 32 + frow) * ROWB;
@@ -205,9 +206,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
                 boff = (((e >> 2) ^ fsw) * 16) + (e & 3) * 4;
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
+            for (int i = 0; i < TM; ++i) {
+                if (DBG >= 6) { af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(smem + (lane & 31) * ROWB); asm volatile("" : "+v"(af[i])); }
+                else af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
+            }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
+            for (int j = 0; j < TN; ++j) {
+                if (DBG >= 6) { bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(smem + (lane & 31) * ROWB + 16); asm volatile("" : "+v"(bf[j])); }
+                else bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -249,12 +256,12 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
     }
 }
 
-struct Tune { int target_blocks; int stages; int remap; };
+struct Tune { int target_blocks; int wide; int remap; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{768, 3, -1};   // K slicing only for grids below half the chip (see choose_ksplit)
+        Tune v{352, 1, -1};   // K slicing only for grids below half the chip (see choose_ksplit)
         if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
-        if (const char *e = getenv("YOLO2_IGEMM_STAGES")) v.stages = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_WIDE")) v.wide = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
         return v;
     }();
@@ -263,27 +270,33 @@ static const Tune &tune() {   // tuning knobs (defaults = measured best); env ov
 // number of K slices: when the M x N tile grid alone cannot fill 256 CUs with ~2-3 resident workgroups
 // each, slice K so that it does, keeping >= 8 K tiles per slice
 static int choose_ksplit(int tiles, int nk, int target) {
-    // measured (profiles/r01_conv_layers_microbench.txt): pays for the 88-tile data gradients and for the 176-tile
-    // layers with a very long reduction (conv20: 864 K tiles); elsewhere atomics + the finishing pass cost more
-    if (target <= 0 || nk < 32 || !(tiles <= 128 || (tiles <= 192 && nk >= 512))) return 1;
+    // measured (profiles/): pays for the 88-tile data gradients; elsewhere atomics + the finishing pass cost more than
+    // the 8-wave / wide-K variants gain
+    if (target <= 0 || nk < 128 || tiles > 128) return 1;
     int ks = (target + tiles - 1) / tiles;
     int max_ks = nk / 8;
     if (ks > max_ks) ks = max_ks;
     return ks < 1 ? 1 : ks;
 }
 
-#define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, gridv)                                                          \
-    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv><<<gridv, 256, 0, st>>>(                                  \
+#define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                                \
+    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv><<<gridv, NWv * 64, 0, st>>>(                \
         (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap)
-#define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, gridv)                                   \
+// kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
+#define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
     do {                                                                               \
         if (ksize == 3) {                                                              \
-            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, true, gridv);               \
-            else Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, false, gridv);                    \
+            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, true, 4, NWv, gridv);       \
+            else Y2_IGEMM(BNv, WGNv, NSv, 3, SPLITv, false, 4, NWv, gridv);            \
         } else {                                                                       \
-            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, true, gridv);               \
-            else Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, false, gridv);                    \
+            if (ctail) Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, true, 4, NWv, gridv);       \
+            else Y2_IGEMM(BNv, WGNv, NSv, 1, SPLITv, false, 4, NWv, gridv);            \
         }                                                                              \
+    } while (0)
+#define Y2_IGEMM_KS_WIDE(SPLITv, gridv)                                                 \
+    do {                                                                               \
+        if (ksize == 3) Y2_IGEMM(128, 2, 3, 3, SPLITv, false, 8, 8, gridv);            \
+        else Y2_IGEMM(128, 2, 3, 1, SPLITv, false, 8, 8, gridv);                       \
     } while (0)
 
 template <typename T>
@@ -300,42 +313,35 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
     const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
     if (Nf > 64) {
+        // 128 x 128 tile, 8 waves (4 x 2, each 32 x 64): two waves per SIMD even when a CU holds a single workgroup.
+        // Grids of <= 256 tiles (the 13x13 / 26x26 stages at batch 16) cannot fill the chip with workgroups, so they
+        // take 128-byte K rows (16 MFMAs per wave between barriers, 96 KiB ring, one workgroup per CU); larger grids
+        // keep 64-byte rows (48 KiB ring, 3 workgroups per CU).  Measured in profiles/r01_igemm_variants.txt.
         const int NT = cdiv(Nf, 128);
-        const int nk = ksize * ksize * cdiv(Cp, BK);
-        int ks = ws ? choose_ksplit(MT * NT, nk, tu.target_blocks) : 1;
+        // K slicing (grids <= 128 tiles with a long reduction) multiplies the workgroup count, so it pairs with the
+        // narrow variant (3 workgroups per CU); unsliced small grids take the wide one.
+        int ks = ws ? choose_ksplit(MT * NT, ksize * ksize * cdiv(Cp, 4 * VEC), tu.target_blocks) : 1;
         if (ks > 1 && (size_t)M * Nf * sizeof(float) > ws_bytes) ks = 1;
+        const bool wide = tu.wide && ks == 1 && MT * NT <= 256 && Cp % (8 * VEC) == 0;
         if (ks > 1) {
             if (hipMemsetAsync(ws, 0, (size_t)M * Nf * sizeof(float), st) != hipSuccess) return 1;
             dim3 grid(MT * NT, ks);
-            if (tu.stages == 4) Y2_IGEMM_KS_CT(128, 2, 4, true, grid);
-            else if (tu.stages == 2) Y2_IGEMM_KS_CT(128, 2, 2, true, grid);
-            else Y2_IGEMM_KS_CT(128, 2, 3, true, grid);
+            Y2_IGEMM_KS_CT(128, 2, 3, true, 4, grid);     // 4-wave workgroups: 3 per CU, measured best with slicing
             long total = (long)M * Nf;
             int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo);
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
-            static const int dbg = getenv("YOLO2_IGEMM_DBG") ? atoi(getenv("YOLO2_IGEMM_DBG")) : 0;
-            if constexpr (sizeof(T) == 2) {
-                if (dbg && ksize == 3 && !ctail) {
-                    if (dbg == 1) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 1><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
-                    else if (dbg == 2) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 2><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
-                    else if (dbg == 3) conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 3><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
-                    else conv_igemm_kernel<T, 128, 2, 3, 3, false, false, 4><<<grid, 256, 0, st>>>((const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap);
-                    return 0;
-                }
-            }
-            if (tu.stages == 4) Y2_IGEMM_KS_CT(128, 2, 4, false, grid);
-            else if (tu.stages == 2) Y2_IGEMM_KS_CT(128, 2, 2, false, grid);
-            else Y2_IGEMM_KS_CT(128, 2, 3, false, grid);
+            if (wide) Y2_IGEMM_KS_WIDE(false, grid);
+            else Y2_IGEMM_KS_CT(128, 2, 3, false, 8, grid);
         }
     } else {
         const int NT = 1;
         ws = nullptr;
         dim3 grid(MT);
-        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, false, grid);
-        else Y2_IGEMM_KS_CT(32, 1, 3, false, grid);
+        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, false, 4, grid);
+        else Y2_IGEMM_KS_CT(32, 1, 3, false, 4, grid);
     }
     return 0;
 }
