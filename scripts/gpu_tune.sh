@@ -1,7 +1,10 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -2
 {
-for d in 0 9 10 11; do YOLO2_KSPLIT_BLOCKS=0 YOLO2_IGEMM_DBG=$d python scripts/conv_bench.py "dbg$d"; done
+for cfg in "0 0" "1 0" "1 512" "1 1024" "1 2048"; do set -- $cfg
+YOLO2_WGRAD_NW8=$1 YOLO2_WGRAD_BLOCKS=$2 python scripts/conv_bench.py "wgrad nw8=$1 blocks=$2"
+done
 } > gpurun_out/conv_bench.log 2>&1
 python - <<'PY'
 txt=open('gpurun_out/conv_bench.log').read().split('\n')
@@ -10,7 +13,8 @@ for l in txt:
     if l.startswith('layer'): cur=l.split(')')[-1].strip(); runs[cur]={}
     elif l.startswith('conv') and cur: runs[cur][l.split()[0]]=l[8:].split()
 names=list(runs)
-print('fwd us:  %-8s'%'layer', ' '.join('%10s'%n for n in names))
+print('wgrad us: %-8s'%'layer', ' '.join('%22s'%n[6:] for n in names))
 for layer in runs[names[0]]:
-    print('         %-8s'%layer, ' '.join('%10s'%runs[n][layer][0].split('|')[0] for n in names))
+    print('          %-8s'%layer, ' '.join('%22s'%runs[n][layer][-1].split('|')[0] for n in names))
 PY
+grep totals gpurun_out/conv_bench.log

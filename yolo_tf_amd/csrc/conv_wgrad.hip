@@ -26,8 +26,8 @@
 
 #define Y2_OOB 0x80000000u
 
-template <typename T, int BC, int BNN, int VARIANT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(
+template <typename T, int BC, int BNN, int VARIANT, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W,
     int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap) {
     constexpr int VEC = 16 / sizeof(T);
@@ -35,11 +35,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     constexpr int XROWB = BC * sizeof(T), YROWB = BNN * sizeof(T);   // bytes per pixel row of a tile
     constexpr int XCH = XROWB / 16, YCH = YROWB / 16;  // 16-byte chunks per row
     constexpr int XRPI = 1024 / XROWB, YRPI = 1024 / YROWB;           // pixel rows per DMA instruction
-    constexpr int X_IT = BKP / XRPI / 4, Y_IT = BKP / YRPI / 4;       // DMA instructions per wave per tile
+    constexpr int X_IT = BKP / XRPI / NW, Y_IT = BKP / YRPI / NW;     // DMA instructions per wave per tile
     constexpr int LOADS = X_IT + Y_IT;
     constexpr int NSTAGE = 3;
     constexpr int XBYTES = BKP * XROWB, STAGE = XBYTES + BKP * YROWB;
-    constexpr int TM = BC / 64, TN = BNN / 64;         // 2x2 waves, each (BC/2) x (BNN/2)
+    constexpr int WGM = NW / 2;                        // waves arranged WGM x 2 over the (c, n) tile
+    constexpr int TM = BC / WGM / 32, TN = BNN / 64;
     constexpr int KSTEP = sizeof(T) == 2 ? 16 : 2;
     static_assert(X_IT >= 1 && Y_IT >= 1, "tile too small for one DMA piece per wave");
     // swizzle: chunk ^= 4 * ((row / rows_per_bank_line) % (row_bytes / 64)); identity for rows >= 512 B
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    static_assert(TM >= 1 && TN >= 1, "tile");
     // Block -> (tile, pixel range).  All tiles (tap, c-tile, n-tile) of one pixel range read the same X / dY
     // rows, so they are placed on ONE XCD (the dispatcher puts block b on XCD b % 8; observed, speed only):
     // XCD x walks the pixel ranges y = x, x+8, ... and for each runs all tiles back to back, which keeps a
@@ -262,7 +264,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     // less atomic traffic; more blocks = more latency hiding).  Measured on the Darknet-19 shapes
     // (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
     // blocks for the 128-wide tile / ~1024 for the 64-wide one; with fewer ranges (13x13 stages) it would
-    // leave XCDs idle, so those keep the plain mapping at ~1024 blocks.
+    // leave XCDs idle, so those keep the plain mapping (~512 blocks of 8 waves for the 128-wide tile).
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
     static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
     const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
@@ -275,7 +277,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
         if (ks < 8) remap = 0;
     }
     if (!remap) {
-        if (env_target <= 0) target = 1024;
+        if (env_target <= 0) target = BC >= 128 ? 512 : 1024;
         ks = cdiv(target, tiles);
         if (ks > max_ks) ks = max_ks;
     }
@@ -285,6 +287,13 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     if (remap && ks % 8 != 0) remap = (ks >= 8);              // rounding may have changed the count; ragged tail is fine
     dim3 grid(remap ? tiles * (cdiv(ks, 8) * 8) : tiles * ks);
     const unsigned x_bytes = (unsigned)((size_t)M * ldx * sizeof(T)), y_bytes = (unsigned)((size_t)M * ldy * sizeof(T));
+    static const int nw8 = getenv("YOLO2_WGRAD_NW8") ? atoi(getenv("YOLO2_WGRAD_NW8")) : 1;
+    if constexpr (BC >= 128) {
+        if (g_wgrad_variant == 0 && nw8) {
+            conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
+            return;
+        }
+    }
     if (g_wgrad_variant == 0)
         conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
     else
