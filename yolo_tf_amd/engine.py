@@ -155,7 +155,12 @@ class Engine(object):
         self.conv_ws = torch.zeros(min(max(max_y, 1), 8 * 1024 * 1024), dtype=torch.float32, device=dev)
         self.ws = torch.zeros(1026 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
-            self.dy_scratch = torch.zeros(max_y, dtype=T, device=dev)
+            # dY scratch ring: the filter gradient of layer L runs on a side stream concurrently with the data gradient
+            # (and the following layers' backward) on the main stream, so dY(L) must outlive the next layers' writes
+            self.dy_ring = [torch.zeros(max_y, dtype=T, device=dev) for _ in range(3)]
+            self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
+            self.side_stream = torch.cuda.Stream(device=dev)
+            self.overlap_wgrad = True
             self.tmp_grad = {}
         self.img = None
 
@@ -257,10 +262,17 @@ class Engine(object):
         return tmp, ld, (lambda: ops.add_inplace(gb, tmp, n))
 
     def backward(self, on_layer_done=None):
-        """Reverse sweep from the gradient already stored for the graph output (written by loss())."""
+        """Reverse sweep from the gradient already stored for the graph output (written by loss()).
+        Per convolution: BN/leaky backward -> dY, then the filter gradient on the side stream overlapped with the data
+        gradient (and everything after it) on the main stream: at batch 16 the 13x13 / 26x26 stages launch grids
+        that cannot fill the chip on their own.  ``on_layer_done(op, event)`` is called once a layer's parameter
+        gradients are enqueued; ``event`` (or None) completes when they are final."""
         B = self.B
         written = set()
         inputs = set(self.graph.inputs.values())
+        main = torch.cuda.current_stream()
+        side = self.side_stream if self.overlap_wgrad else None
+        slot = 0
         for op in reversed(self.graph.ops):
             kind = op['kind']
             if kind == 'conv':
@@ -276,21 +288,38 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
                                             self.gvar[op['beta'].name], self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
-                    dy = self.dy_scratch
+                    slot = (slot + 1) % 3
+                    dy = self.dy_ring[slot]
+                    if self.dy_free[slot] is not None:
+                        main.wait_event(self.dy_free[slot])       # the filter gradient that last read this buffer is done
                     ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
                                            self.gvar[op['beta'].name], dy, M, cout, BN_EPS, LEAKY_ALPHA)
+                    ring = True
                 else:
                     dy = gob
                     assert ldgo == ldy
                     ops.bias_grad(dy, ldy, self.gvar[op['biases'].name], self.ws, M, cout)
-                ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
+                    ring = False
+                done = None
+                if side is not None:
+                    ready = torch.cuda.Event()
+                    ready.record(main)
+                    side.wait_event(ready)
+                    with torch.cuda.stream(side):
+                        ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
+                        done = torch.cuda.Event()
+                        done.record(side)
+                    if ring:
+                        self.dy_free[slot] = done
+                else:
+                    ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
                 if x not in inputs:
                     dst, ldd, fin = self._grad_sink(x, written)
                     self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
                     if fin:
                         fin()
                 if on_layer_done is not None:
-                    on_layer_done(op)
+                    on_layer_done(op, done)
             elif kind == 'pool':
                 x, out = op['x'], op['out']
                 dst, ldd, fin = self._grad_sink(x, written)
@@ -308,6 +337,8 @@ class Engine(object):
             elif kind == 'concat':
                 for v in op['inputs']:
                     written.add(v)           # their gradients are slices of the concat gradient
+        if side is not None:
+            main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
 
     def output(self):
         return self.graph.ops[-1]['out']

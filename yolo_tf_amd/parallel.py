@@ -56,13 +56,19 @@ class GradReducer(object):
         self.comm_stream = torch.cuda.Stream() if self.use_stream else None
         self.next_bucket = 0
         self.handles = []
+        self.pending_events = []
 
     def begin(self):
         self.next_bucket = 0
         self.handles = []
+        self.pending_events = []
 
-    def ready_upto(self, end_offset):
-        """Backward has finished every gradient in [0, end_offset): launch the complete buckets."""
+    def ready_upto(self, end_offset, event=None):
+        """Backward has enqueued every gradient in [0, end_offset): launch the complete buckets.  ``event`` (optional)
+        completes when gradients enqueued on another stream (the engine's filter-gradient stream) are final; the
+        communication stream waits for every such event seen so far plus the caller's current stream."""
+        if event is not None:
+            self.pending_events.append(event)
         if self.world == 1:
             return
         while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][1] <= end_offset:
@@ -75,6 +81,9 @@ class GradReducer(object):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
+            for pe in self.pending_events:
+                self.comm_stream.wait_event(pe)
+            self.pending_events = []
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
         else:

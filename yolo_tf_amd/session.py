@@ -63,7 +63,7 @@ class TrainSession(object):
                  self.B, m.cell_height, m.cell_width, self.A, self.C)
         if self.reducer is not None:
             self.reducer.begin()
-            e.backward(on_layer_done=lambda op: self.reducer.ready_upto(self._layer_end[op['name']]))
+            e.backward(on_layer_done=lambda op, ev: self.reducer.ready_upto(self._layer_end[op['name']], ev))
             self.reducer.finish()
         else:
             e.backward()
