@@ -66,9 +66,13 @@ int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW,
                        int dtype, void *stream);
 
 /* HWIO f32 master weights [k,k,Cin,Cout] -> the two K-contiguous operand layouts:
- *   Ffwd [Cout][k*k*ldcin]  : Ffwd[n][(r*k+s)*ldcin + c]      = W[r,s,c,n]
- *   Fdgr [Cin ][k*k*ldcout] : Fdgr[c][(r*k+s)*ldcout + n]     = W[k-1-r,k-1-s,c,n]
- * (zero in the padding lanes).  Either output may be NULL. */
+ *   Ffwd [Cout][k*k*ldcin]  : Ffwd[n][koff(r*k+s, c, ldcin)]  = W[r,s,c,n]
+ *   Fdgr [Cin ][k*k*ldcout] : Fdgr[c][koff(r*k+s, n, ldcout)] = W[k-1-r,k-1-s,c,n]
+ * (zero in the padding lanes).  Either output may be NULL.  K order inside a row, for ld channels and t = k*k taps:
+ *   koff(tap, c, ld) = (c / kc) * t * kc + tap * kc + c % kc,   kc = 64 if (t > 1 and ld % 64 == 0) else ld
+ * i.e. 64-channel chunk outermost, then tap, then channel: the 9 shifted reads of a pixel-tile x 64-channel slab are
+ * consecutive K steps, so they hit in L2 (tap-major order measured 15x the algorithmic fabric traffic in the 13x13
+ * stages).  The layout is an implementation detail shared by yolo2_filter_prep* and yolo2_conv2d*. */
 int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin, int ldcin,
                       int Cout, int ldcout, int dtype, void *stream);
 

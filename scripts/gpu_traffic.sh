@@ -1,0 +1,18 @@
+#!/bin/bash
+# Final-state profiles: kernel trace (product config + single-stream), then HBM traffic counters in separate PMC passes.
+R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
+B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timer --no-detect"
+rm -rf $R/gpurun_out/prof $R/gpurun_out/prof1s $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o run -- $B > $R/gpurun_out/prof.log 2>&1
+grep '"metric"' $R/gpurun_out/prof.log | cut -c1-200
+python $R/scripts/prof_summary.py $R/gpurun_out/prof 5 > $R/gpurun_out/prof_summary.md
+YOLO2_OVERLAP_WGRAD=0 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof1s -o run -- $B > $R/gpurun_out/prof1s.log 2>&1
+grep '"metric"' $R/gpurun_out/prof1s.log | cut -c1-200
+python $R/scripts/prof_summary.py $R/gpurun_out/prof1s 5 > $R/gpurun_out/prof1s_summary.md
+B2="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-detect"
+YOLO2_OVERLAP_WGRAD=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o r -- $B2 > $R/gpurun_out/pmc_fetch.log 2>&1
+YOLO2_OVERLAP_WGRAD=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o r -- $B2 > $R/gpurun_out/pmc_write.log 2>&1
+python $R/scripts/pmc_traffic.py $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write > $R/gpurun_out/traffic_summary.md 2>&1
+head -60 $R/gpurun_out/traffic_summary.md
+# keep the merged-back payload small
+find $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write $R/gpurun_out/prof $R/gpurun_out/prof1s -name "*kernel_trace.csv" -size +20M -delete

@@ -77,6 +77,8 @@ CONV_SHAPES = [
     (2, 26, 26, 64, 160, 3),    # two N tiles, M tail (1352 rows)
     (1, 8, 8, 24, 64, 3),       # BN=64 tile, channel tail inside a K step
     (3, 5, 7, 136, 72, 3),      # odd extents, several K steps per tap
+    (1, 13, 13, 192, 128, 3),   # three 64-channel K chunks forward, two in the data gradient
+    (2, 9, 11, 320, 200, 3),    # five chunks; data gradient single-chunk (ldy = 200)
 ]
 
 
@@ -176,28 +178,38 @@ def test_tr16_layout(ops):
     assert np.array_equal(out, exp), 'unexpected transpose-read layout:\n%s' % out
 
 
-def test_filter_prep_exact(ops):
+def _k_order(x, taps, ld):
+    """[rows][taps][ld] (tap-major) -> the kernels' K order (include/yolo2_hip.h): 64-channel chunk, tap, channel in chunk
+    when ld % 64 == 0 and taps > 1; otherwise unchanged."""
+    rows = x.shape[0]
+    if taps == 1 or ld % 64:
+        return x.reshape(rows, taps * ld)
+    return x.reshape(rows, taps, ld // 64, 64).transpose(0, 2, 1, 3).reshape(rows, taps * ld)
+
+
+@pytest.mark.parametrize('dims', [(3, 5, 11, 8, 16), (3, 100, 70, 128, 72), (3, 64, 192, 64, 192), (1, 128, 64, 128, 64)])
+def test_filter_prep_exact(ops, dims):
     rng = np.random.RandomState(0)
-    k, Cin, Cout = 3, 5, 11
-    ldcin, ldcout = 8, 16
+    k, Cin, Cout, ldcin, ldcout = dims
+    taps = k * k
     w = rng.randn(k, k, Cin, Cout).astype(np.float32)
-    Ff = torch.full((Cout * 9 * ldcin,), 7.0, dtype=torch.float32, device='cuda')
-    Fd = torch.full((Cin * 9 * ldcout,), 7.0, dtype=torch.float32, device='cuda')
+    Ff = torch.full((Cout * taps * ldcin,), 7.0, dtype=torch.float32, device='cuda')
+    Fd = torch.full((Cin * taps * ldcout,), 7.0, dtype=torch.float32, device='cuda')
     ops.filter_prep(dev(w), Ff, Fd, k, Cin, ldcin, Cout, ldcout, torch.float32)
     torch.cuda.synchronize()
-    ef = np.zeros((Cout, 9, ldcin), np.float32)
-    ef[:, :, :Cin] = w.reshape(9, Cin, Cout).transpose(2, 0, 1)
-    ed = np.zeros((Cin, 9, ldcout), np.float32)
-    ed[:, :, :Cout] = w[::-1, ::-1].reshape(9, Cin, Cout).transpose(1, 0, 2)
-    assert np.array_equal(host(Ff).reshape(Cout, 9, ldcin), ef)
-    assert np.array_equal(host(Fd).reshape(Cin, 9, ldcout), ed)
+    ef = np.zeros((Cout, taps, ldcin), np.float32)
+    ef[:, :, :Cin] = w.reshape(taps, Cin, Cout).transpose(2, 0, 1)
+    ed = np.zeros((Cin, taps, ldcout), np.float32)
+    ed[:, :, :Cout] = w[::-1, ::-1].reshape(taps, Cin, Cout).transpose(1, 0, 2)
+    assert np.array_equal(host(Ff).reshape(Cout, -1), _k_order(ef, taps, ldcin))
+    assert np.array_equal(host(Fd).reshape(Cin, -1), _k_order(ed, taps, ldcout))
 
 
 def test_filter_prep_batch_matches_per_layer(ops):
     import ctypes
     from yolo_tf_amd._lib import FilterDesc
     rng = np.random.RandomState(1)
-    layers = [(3, 3, 32), (3, 32, 64), (1, 128, 64), (3, 40, 125), (1, 1024, 125)]
+    layers = [(3, 3, 32), (3, 32, 64), (1, 128, 64), (3, 40, 125), (1, 1024, 125), (3, 128, 192)]
     for tdtype in (torch.float32, torch.bfloat16):
         arr = (FilterDesc * len(layers))()
         keep, first = [], 0

@@ -36,6 +36,18 @@ int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H,
         }                                                                           \
     } while (0)
 
+// K order of the MFMA filter operands (Ffwd / Fdgr rows): channel chunk outermost, tap, channel inside the chunk.
+// With taps outermost a 3x3 layer re-reads its input tile 9 times with the whole channel extent in between, which
+// overflows the 4 MiB XCD L2 in the 13x13 stages (measured 15x the algorithmic fabric traffic); with 64-channel
+// chunks the 9 shifted re-reads of a 128-pixel x 64-channel slab are back to back.  Rows whose channel extent is
+// not a multiple of 64 keep a single chunk (= tap-major).
+#define Y2_KCHUNK 64
+__host__ __device__ static inline int y2_kchunk(int ld, int taps) { return (taps > 1 && ld % Y2_KCHUNK == 0) ? Y2_KCHUNK : ld; }
+__host__ __device__ static inline long y2_filter_koff(int tap, int c, int ld, int taps) {
+    const int kc = y2_kchunk(ld, taps);
+    return (long)(c / kc) * taps * kc + (long)tap * kc + c % kc;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // 16-byte vector of T: 4 floats or 8 bf16

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
     constexpr int BM = 128;
+    constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BK = CH * VEC;           // CH = 16-byte chunks per tile row: 4 -> 32 bf16 / 16 f32 per K step
     constexpr int ROWB = CH * 16;          // bytes per tile row
@@ -129,8 +130,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int kpt = (Cp + BK - 1) / BK;   // K tiles per tap
-    const int nk = KS * KS * kpt;
+    // K order (common.h y2_filter_koff): channel chunk, tap, BK-wide step inside the chunk
+    const int KC = y2_kchunk(Cp, TAPS);
+    const int kpc = (KC + BK - 1) / BK;   // K tiles per (chunk, tap)
+    const int nk = (Cp / KC) * TAPS * kpc;
     int kt_beg = 0, kt_end = nk;
     if (SPLITK) {
         const int per = (nk + gridDim.y - 1) / gridDim.y;
@@ -141,15 +144,16 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
 
     // issue cursor (wave-uniform scalars), NSTAGE-1 tiles ahead of the compute cursor
     int kt_issue = kt_beg;
-    int i_tap = kt_beg / kpt;
-    int i_c0 = (kt_beg - i_tap * kpt) * BK;
+    int i_chunk0 = (kt_beg / (TAPS * kpc)) * KC;            // first channel of the chunk
+    int i_tap = (kt_beg / kpc) % TAPS;
+    int i_c0 = i_chunk0 + (kt_beg % kpc) * BK;              // first channel of the step
     int i_dh = i_tap / KS - PAD, i_dw = i_tap % KS - PAD;
     int i_stage = 0;
     const unsigned cp_bytes = (unsigned)Cp * (unsigned)sizeof(T);
     auto issue_next = [&]() {
         const unsigned tapbit = 1u << i_tap;
         const unsigned offA = (unsigned)((i_dh * W + i_dw) * ldp + i_c0) * (unsigned)sizeof(T);   // may wrap: added mod 2^32
-        const unsigned offB = (unsigned)(i_tap * Cp + i_c0) * (unsigned)sizeof(T);
+        const unsigned offB = (unsigned)(i_chunk0 * TAPS + i_tap * KC + (i_c0 - i_chunk0)) * (unsigned)sizeof(T);
         const unsigned c0b = (unsigned)i_c0 * (unsigned)sizeof(T);
         unsigned char *As = smem + i_stage * STAGE;
         unsigned char *Bs = As + BM * ROWB;
@@ -169,10 +173,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         ++kt_issue;
         i_stage = (i_stage + 1 == NSTAGE) ? 0 : i_stage + 1;
         i_c0 += BK;
-        if (i_c0 >= Cp) {
-            i_c0 = 0;
-            ++i_tap;
-            if (++i_dw > PAD) { i_dw = -PAD; ++i_dh; }
+        if (i_c0 >= i_chunk0 + KC) {
+            if (++i_tap == TAPS) { i_tap = 0; i_chunk0 += KC; i_dh = -PAD; i_dw = -PAD; }
+            else if (++i_dw > PAD) { i_dw = -PAD; ++i_dh; }
+            i_c0 = i_chunk0;
         }
     };
 #pragma unroll

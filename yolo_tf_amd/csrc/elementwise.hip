@@ -38,7 +38,7 @@ __global__ void filter_fwd_kernel(const float *__restrict__ Wt, T *__restrict__ 
     const long Kf = (long)taps * ldcin;
     for (int i = ty; i < 32; i += 8) {
         int n = n0 + i, c = c0 + tx;
-        if (n < Cout && c < ldcin) F[n * Kf + (long)tap * ldcin + c] = (T)tile[tx][i];
+        if (n < Cout && c < ldcin) F[n * Kf + y2_filter_koff(tap, c, ldcin, taps)] = (T)tile[tx][i];
     }
 }
 template <typename T>
@@ -50,7 +50,7 @@ __global__ void filter_dgrad_kernel(const float *__restrict__ Wt, T *__restrict_
         int tp = (int)(r % taps);
         int c = (int)(r / taps);
         float v = n < Cout ? Wt[((long)(taps - 1 - tp) * Cin + c) * Cout + n] : 0.f;
-        F[i] = (T)v;
+        F[c * (long)taps * ldcout + y2_filter_koff(tp, n, ldcout, taps)] = (T)v;
     }
 }
 
@@ -102,7 +102,7 @@ __global__ void filter_prep_batch_kernel(const yolo2_filter_desc *__restrict__ d
         const long Kf = (long)taps * d.ldcin;
         for (int i = ty; i < 32; i += 8) {
             int nn = n0 + i, c = c0 + tx;
-            if (nn < d.cout && c < d.ldcin) Ff[nn * Kf + (long)tap * d.ldcin + c] = (T)tile[tx][i];
+            if (nn < d.cout && c < d.ldcin) Ff[nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps)] = (T)tile[tx][i];
         }
     }
     if (Fd) {
@@ -110,7 +110,7 @@ __global__ void filter_prep_batch_kernel(const yolo2_filter_desc *__restrict__ d
         const int tp = taps - 1 - tap;            // flipped tap
         for (int i = ty; i < 32; i += 8) {
             int c = c0 + i, nn = n0 + tx;
-            if (c < d.cin && nn < d.ldcout) Fd[c * Kd + (long)tp * d.ldcout + nn] = (T)tile[i][tx];
+            if (c < d.cin && nn < d.ldcout) Fd[c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps)] = (T)tile[i][tx];
         }
     }
 }

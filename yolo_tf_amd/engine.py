@@ -14,6 +14,8 @@ Memory layout decisions (288 GB HBM: nothing is recomputed, nothing is re-alloca
     slices of the concat buffer (producers write in place, no copy kernel).
 """
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -61,6 +63,7 @@ class Engine(object):
         self._alloc_activations()
         self.init_variables(seed)
         self._filters_dirty = True
+        self._phase = 'fwd'          # 'fwd' | 'dgrad': which sweep a conv launch belongs to (timer tag)
         self.kernel_timer = None     # optional bench.KernelTimer: HIP events around the dominant conv kernel
 
     # ---------------------------------------------------------------- variables
@@ -160,7 +163,7 @@ class Engine(object):
             self.dy_ring = [torch.zeros(max_y, dtype=T, device=dev) for _ in range(3)]
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
             self.side_stream = torch.cuda.Stream(device=dev)
-            self.overlap_wgrad = True
+            self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
             self.tmp_grad = {}
         self.img = None
 
@@ -171,7 +174,7 @@ class Engine(object):
         ``real_k`` = unpadded reduction length, for the algorithmic FLOP count."""
         t = self.kernel_timer if Nf > 64 else None
         if t is not None:
-            t.start(2.0 * self.B * H * W * Nf * real_k)
+            t.start(2.0 * self.B * H * W * Nf * real_k, self._phase)
         ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
         if t is not None:
             t.stop()
@@ -270,6 +273,7 @@ class Engine(object):
         B = self.B
         written = set()
         inputs = set(self.graph.inputs.values())
+        self._phase = 'dgrad'
         main = torch.cuda.current_stream()
         side = self.side_stream if self.overlap_wgrad else None
         slot = 0
@@ -337,6 +341,7 @@ class Engine(object):
             elif kind == 'concat':
                 for v in op['inputs']:
                     written.add(v)           # their gradients are slices of the concat gradient
+        self._phase = 'fwd'
         if side is not None:
             main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
 
