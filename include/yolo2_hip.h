@@ -53,7 +53,10 @@ int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O,
 /* Same convolution with a caller-owned f32 workspace: when the M x N tile grid cannot fill the chip
  * (13x13 / 26x26 stages at small batch) the K loop is sliced across workgroups, partial tiles are
  * accumulated in `ws` (>= B*H*W*Nf floats for slicing to be considered; smaller = no slicing) and a
- * finishing kernel writes O.  Results agree with yolo2_conv2d to f32 rounding of the partial sums. */
+ * finishing kernel writes O.  Grids below one tile per CU with a long reduction instead run "stream-K": one
+ * workgroup per CU, equal contiguous shares of the flat (tile, K step) space, partial tiles parked in `ws`
+ * (needs >= (1024 + CUs*128*128) floats = 16.8 MB on MI355X) and fixed up inside the same launch.
+ * `ws` may hold anything on entry.  Results agree with yolo2_conv2d to f32 rounding of the partial sums. */
 int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws,
                     size_t ws_bytes, int B, int H, int W, int Cp, int ldp, int Nf, int ldo,
                     int ksize, int dtype, void *stream);

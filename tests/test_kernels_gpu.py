@@ -120,7 +120,8 @@ def test_conv_dgrad(ops, shape, mode):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
-@pytest.mark.parametrize('shape', [(2, 13, 13, 512, 256, 3), (1, 13, 13, 1024, 125, 1), (2, 26, 26, 256, 136, 3)])
+@pytest.mark.parametrize('shape', [(2, 13, 13, 512, 256, 3), (1, 13, 13, 1024, 125, 1), (2, 26, 26, 256, 136, 3),
+                                   (8, 13, 13, 1024, 500, 3), (16, 13, 13, 3072, 1000, 1)])   # the last two take the stream-K path
 def test_conv_forward_ksliced(ops, shape, mode):
     """yolo2_conv2d_ws: K loop sliced across workgroups (small M x N grids), f32 partial tiles + finishing kernel."""
     B, H, W, Cin, Cout, k = shape
@@ -136,7 +137,7 @@ def test_conv_forward_ksliced(ops, shape, mode):
     F = torch.zeros(Cout * k * k * Cin, dtype=tdtype, device='cuda')
     ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, ldo, tdtype)
     O = torch.zeros(B * H * W * ldo, dtype=tdtype, device='cuda')
-    ws = torch.full((B * H * W * Cout + 64,), 5.0, dtype=torch.float32, device='cuda')    # dirty on purpose
+    ws = torch.full((max(B * H * W * Cout + 64, 1024 + 256 * 128 * 128),), 5.0, dtype=torch.float32, device='cuda')    # dirty on purpose
     ops.conv2d_ws(dev(x, tdtype), F, dev(bias), O, ws, B, H, W, Cin, Cin, Cout, ldo, k)
     torch.cuda.synchronize()
     y = host(O).reshape(B, H, W, ldo)

@@ -48,10 +48,13 @@ template <> struct Mma<float> {
     }
 };
 
+#define Y2_STREAM_FLAG_WORDS 1024     // stream-K workspace: one flag word per workgroup, then one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
 // DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
-template <typename T, int BN, int WGN, int NSTAGE, int KS, bool SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4>
+// SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
+// CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
+template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
@@ -79,17 +82,54 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    int tile = blockIdx.x;
-    if (remap) {   // one contiguous run of tiles per XCD (bijective for any grid size)
-        const int ntile = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = ntile >> 3, r = ntile & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int MT = (M + BM - 1) / BM;
+    // K order (common.h y2_filter_koff): channel chunk, tap, BK-wide step inside the chunk
+    const int KC = y2_kchunk(Cp, TAPS);
+    const int kpc = (KC + BK - 1) / BK;   // K tiles per (chunk, tap)
+    const int nk = (Cp / KC) * TAPS * kpc;
+    // stream-K: this workgroup's range of the flat (tile, K step) space; workgroup b runs on XCD b % 8 and the
+    // ranges of one XCD are contiguous, tiles ordered filter-tile-major (an XCD works on ~NT/8 filter slabs)
+    long su = 0, su_end = 0, su_total = 0;
+    int wx = 0;
+    if (SPLITK == 2) {
+        su_total = (long)MT * NT * nk;
+        const int G = gridDim.x, b = blockIdx.x;
+        wx = (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3);
+        su = wx * su_total / G;
+        su_end = (wx + 1) * su_total / G;
     }
-    const int nt = tile % NT, mt = tile / NT;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int lrow = lane / CH, lslot = lane % CH;
 
     const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
+    const int lrow = lane / CH, lslot = lane % CH;
+
+  for (bool first_seg = true;; first_seg = false) {
+    int nt, mt, kt_beg = 0, kt_end = nk;
+    if (SPLITK == 2) {
+        if (su >= su_end) break;
+        const int t = (int)(su / nk);
+        kt_beg = (int)(su - (long)t * nk);
+        kt_end = (int)min((long)nk, kt_beg + (su_end - su));
+        su += kt_end - kt_beg;
+        nt = t / MT;
+        mt = t - nt * MT;
+        if (!first_seg) __syncthreads();      // every wave is done reading the previous segment's LDS stages
+    } else {
+        int tile = blockIdx.x;
+        if (remap) {   // one contiguous run of tiles per XCD (bijective for any grid size)
+            const int ntile = gridDim.x, xcd = tile & 7, idx = tile >> 3, q = ntile >> 3, r = ntile & 7;
+            tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        nt = tile % NT;
+        mt = tile / NT;
+        if (SPLITK == 1) {
+            const int per = (nk + gridDim.y - 1) / gridDim.y;
+            kt_beg = blockIdx.y * per;
+            kt_end = min(nk, kt_beg + per);
+            if (kt_beg >= kt_end) return;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
 
     // per-lane source descriptors: byte offset of (row, swizzled chunk) and the set of taps inside the image
     unsigned a_voff[A_IT], a_mask[A_IT], a_cb[A_IT];
@@ -129,18 +169,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // K order (common.h y2_filter_koff): channel chunk, tap, BK-wide step inside the chunk
-    const int KC = y2_kchunk(Cp, TAPS);
-    const int kpc = (KC + BK - 1) / BK;   // K tiles per (chunk, tap)
-    const int nk = (Cp / KC) * TAPS * kpc;
-    int kt_beg = 0, kt_end = nk;
-    if (SPLITK) {
-        const int per = (nk + gridDim.y - 1) / gridDim.y;
-        kt_beg = blockIdx.y * per;
-        kt_end = min(nk, kt_beg + per);
-        if (kt_beg >= kt_end) return;
-    }
 
     // issue cursor (wave-uniform scalars), NSTAGE-1 tiles ahead of the compute cursor
     int kt_issue = kt_beg;
@@ -228,12 +256,59 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         }
     }
 
+    if (SPLITK == 2) {
+        // Stream-K fix-up without atomics.  A workgroup's range is [tail of a tile][whole tiles][head of a tile]; the
+        // workgroup holding K step 0 of a tile owns it.  A tail (kt_beg > 0) is always the FIRST segment of its
+        // workgroup: it is parked in that workgroup's slot of the workspace (accumulator-register layout, coalesced)
+        // and published through a flag, before the workgroup can wait for anything -- so owners only ever wait for
+        // work that is never itself blocked.  The owner adds the parked parts of the workgroups after it and writes
+        // the finished tile (+ bias) directly.
+        unsigned *flags = reinterpret_cast<unsigned *>(Oacc);
+        float *slots = Oacc + Y2_STREAM_FLAG_WORDS;
+        constexpr int SLOT = BM * BN;
+        if (kt_beg > 0) {
+            float *mine = slots + (size_t)wx * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // Agent-scope relaxed accesses (sc1: written through / read past the non-coherent per-XCD L2) instead of
+            // release/acquire fences: an agent-scope fence writes back and invalidates the whole XCD L2, which evicts the
+            // filter slabs and input tiles every other workgroup of the XCD is streaming (measured: +100 us per launch).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's slot stores have been acknowledged
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (kt_end < nk) {
+            const long tile_end = su - kt_end + nk;       // su was already advanced past this segment
+            const int G = gridDim.x;
+            long covered = su;
+            for (int p = wx + 1; covered < tile_end; ++p) {
+                if (tid == 0) {
+                    while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                }
+                __syncthreads();
+                const float *theirs = slots + (size_t)p * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += __hip_atomic_load(theirs + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                covered = (long)(p + 1) * su_total / G;
+            }
+        }
+    }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (n >= Nf) continue;
-        const float bv = (!SPLITK && bias) ? bias[n] : 0.f;
+        const float bv = (SPLITK != 1 && bias) ? bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
@@ -241,12 +316,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             for (int r = 0; r < 16; ++r) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m < M) {
-                    if (SPLITK) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
+                    if (SPLITK == 1) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
                     else O[(long)m * ldo + n] = (T)(acc[i][j][r] + bv);
                 }
             }
         }
     }
+    if (SPLITK != 2) break;
+  }
 }
 
 // f32 partial sums [M][Nf] -> O (dtype, pixel stride ldo) + bias
@@ -260,10 +337,16 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
     }
 }
 
-struct Tune { int target_blocks; int wide; int remap; };
+struct Tune { int target_blocks; int wide; int remap; int stream; int cus; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{352, 1, -1};   // K slicing only for grids below half the chip (see choose_ksplit)
+        Tune v{352, 1, -1, 1, 256};   // K slicing only for grids below half the chip (see choose_ksplit)
+        if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            v.cus = prop.multiProcessorCount;
+        if (const char *e = getenv("YOLO2_IGEMM_STREAM_WGS")) v.cus = atoi(e);
         if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_WIDE")) v.wide = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
@@ -327,25 +410,36 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         int ks = ws ? choose_ksplit(MT * NT, ksize * ksize * cdiv(Cp, 4 * VEC), tu.target_blocks) : 1;
         if (ks > 1 && (size_t)M * Nf * sizeof(float) > ws_bytes) ks = 1;
         const bool wide = tu.wide && ks == 1 && MT * NT <= 256 && Cp % (8 * VEC) == 0;
-        if (ks > 1) {
+        // stream-K: a grid that cannot give every CU a tile (13x13 stages at batch 16: 176 tiles, 88 for the narrower
+        // data gradients) is run by exactly one 8-wave wide-row workgroup per CU, each taking an equal contiguous share
+        // of the flat (tile, K step) space (>= 24 K steps each, else the two partial-tile epilogues dominate)
+        const long units = (long)MT * NT * ksize * ksize * (Cp / (8 * VEC));
+        const bool stream = tu.stream && ws && tu.wide && Cp % (8 * VEC) == 0 && MT * NT < tu.cus && units >= 24L * tu.cus &&
+                            tu.cus <= Y2_STREAM_FLAG_WORDS && (Y2_STREAM_FLAG_WORDS + (size_t)tu.cus * 128 * 128) * sizeof(float) <= ws_bytes;
+        if (stream) {
+            if (hipMemsetAsync(ws, 0, Y2_STREAM_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;   // flags only
+            dim3 grid(tu.cus);
+            if (ksize == 3) Y2_IGEMM(128, 2, 3, 3, 2, false, 8, 8, grid);
+            else Y2_IGEMM(128, 2, 3, 1, 2, false, 8, 8, grid);
+        } else if (ks > 1) {
             if (hipMemsetAsync(ws, 0, (size_t)M * Nf * sizeof(float), st) != hipSuccess) return 1;
             dim3 grid(MT * NT, ks);
-            Y2_IGEMM_KS_CT(128, 2, 3, true, 4, grid);     // 4-wave workgroups: 3 per CU, measured best with slicing
+            Y2_IGEMM_KS_CT(128, 2, 3, 1, 4, grid);     // 4-wave workgroups: 3 per CU, measured best with slicing
             long total = (long)M * Nf;
             int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo);
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
-            if (wide) Y2_IGEMM_KS_WIDE(false, grid);
-            else Y2_IGEMM_KS_CT(128, 2, 3, false, 8, grid);
+            if (wide) Y2_IGEMM_KS_WIDE(0, grid);
+            else Y2_IGEMM_KS_CT(128, 2, 3, 0, 8, grid);
         }
     } else {
         const int NT = 1;
         ws = nullptr;
         dim3 grid(MT);
-        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, false, 4, grid);
-        else Y2_IGEMM_KS_CT(32, 1, 3, false, 4, grid);
+        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, 0, 4, grid);
+        else Y2_IGEMM_KS_CT(32, 1, 3, 0, 4, grid);
     }
     return 0;
 }
