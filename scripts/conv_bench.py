@@ -28,7 +28,7 @@ def timeit(fn, n=10):
     return a.elapsed_time(b) / n * 1e3   # us
 
 
-ws = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device='cuda')
+ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
 tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
 print('%-8s %12s %12s %12s   (us | TFLOP/s)  %s' % ('layer', 'fwd', 'dgrad', 'wgrad', tag))
 for name, H, cin, cout, k in LAYERS:

@@ -9,8 +9,6 @@ while IFS= read -r cfg; do
     echo "$cfg rep$rep: $v" | tee -a gpurun_out/ab.log
   done
 done <<CFG
-YOLO2_OVERLAP_WGRAD=1 YOLO2_IGEMM_STREAM=1
-YOLO2_OVERLAP_WGRAD=1 YOLO2_IGEMM_STREAM=0
-YOLO2_OVERLAP_WGRAD=0 YOLO2_IGEMM_STREAM=1
-YOLO2_OVERLAP_WGRAD=0 YOLO2_IGEMM_STREAM=0
+YOLO2_IGEMM_BM256=1
+YOLO2_IGEMM_BM256=0
 CFG

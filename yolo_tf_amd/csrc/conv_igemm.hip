@@ -54,11 +54,11 @@ template <> struct Mma<float> {
 // DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
 // CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
-template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4>
+template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4, int BMv = 128>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
-    constexpr int BM = 128;
+    constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BK = CH * VEC;           // CH = 16-byte chunks per tile row: 4 -> 32 bf16 / 16 f32 per K step
@@ -337,16 +337,20 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
     }
 }
 
-struct Tune { int target_blocks; int wide; int remap; int stream; int cus; };
+struct Tune { int target_blocks; int wide; int remap; int stream; int cus; int stream_max_tiles; int bm256; int bm256_stream_tiles; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{352, 1, -1, 1, 256};   // K slicing only for grids below half the chip (see choose_ksplit)
+        Tune v{352, 1, -1, 1, 256, 255, 1, 0};
+        if (const char *e = getenv("YOLO2_IGEMM_BM256")) v.bm256 = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_BM256_STREAM_TILES")) v.bm256_stream_tiles = atoi(e);   // K slicing only for grids below half the chip (see choose_ksplit)
         if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             v.cus = prop.multiProcessorCount;
         if (const char *e = getenv("YOLO2_IGEMM_STREAM_WGS")) v.cus = atoi(e);
+        v.stream_max_tiles = 3 * v.cus;
+        if (const char *e = getenv("YOLO2_IGEMM_STREAM_MAXTILES")) v.stream_max_tiles = atoi(e);
         if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_WIDE")) v.wide = atoi(e);
         if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
@@ -366,9 +370,10 @@ static int choose_ksplit(int tiles, int nk, int target) {
     return ks < 1 ? 1 : ks;
 }
 
-#define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                                \
-    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv><<<gridv, NWv * 64, 0, st>>>(                \
+#define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
+    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
         (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap)
+#define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
 #define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
     do {                                                                               \
@@ -399,7 +404,20 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     const bool ctail = (Cp % BK) != 0;
     // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
     const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
-    if (Nf > 64) {
+    const int MT2 = cdiv(M, 256), NT2 = cdiv(Nf, 128);
+    const long nk_wide = (Cp % (8 * VEC) == 0) ? (long)ksize * ksize * (Cp / (8 * VEC)) : 0;
+    // Long reductions on under-filled grids (13x13 stages: 1024+ input channels): 256 x 128 tile, 8 waves of 64 x 64
+    // (half the LDS fragment traffic and 25 % less DMA per flop than 32 x 64 per wave), always stream-K.  Measured
+    // (profiles/r01_igemm_bm256.txt): +23 % on the 3072-channel layer; shorter reductions, fuller grids and grids under
+    // 64 tiles (each tile cut into > 4 parts: the owner's serial fix-up) lose.
+    if (Nf > 64 && tu.bm256 && ws && tu.stream && nk_wide >= 128 && MT2 * NT2 >= 64 && MT2 * NT2 <= 3 * tu.cus && tu.cus <= Y2_STREAM_FLAG_WORDS &&
+        (Y2_STREAM_FLAG_WORDS + (size_t)tu.cus * 256 * 128) * sizeof(float) <= ws_bytes) {
+        const int NT = NT2;
+        if (hipMemsetAsync(ws, 0, Y2_STREAM_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;   // flags only
+        dim3 grid(tu.cus);
+        if (ksize == 3) Y2_IGEMM_BM(256, 128, 2, 3, 3, 2, false, 8, 8, grid);
+        else Y2_IGEMM_BM(256, 128, 2, 3, 1, 2, false, 8, 8, grid);
+    } else if (Nf > 64) {
         // 128 x 128 tile, 8 waves (4 x 2, each 32 x 64): two waves per SIMD even when a CU holds a single workgroup.
         // Grids of <= 256 tiles (the 13x13 / 26x26 stages at batch 16) cannot fill the chip with workgroups, so they
         // take 128-byte K rows (16 MFMAs per wave between barriers, 96 KiB ring, one workgroup per CU); larger grids
@@ -412,9 +430,11 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         const bool wide = tu.wide && ks == 1 && MT * NT <= 256 && Cp % (8 * VEC) == 0;
         // stream-K: a grid that cannot give every CU a tile (13x13 stages at batch 16: 176 tiles, 88 for the narrower
         // data gradients) is run by exactly one 8-wave wide-row workgroup per CU, each taking an equal contiguous share
-        // of the flat (tile, K step) space (>= 24 K steps each, else the two partial-tile epilogues dominate)
+        // of the flat (tile, K step) space (>= 24 K steps each, else the two partial-tile epilogues dominate).  Grids of
+        // 1-3 tiles per CU gain only when the reduction is long (>= 96 K steps per tile; measured, profiles/)
         const long units = (long)MT * NT * ksize * ksize * (Cp / (8 * VEC));
-        const bool stream = tu.stream && ws && tu.wide && Cp % (8 * VEC) == 0 && MT * NT < tu.cus && units >= 24L * tu.cus &&
+        const bool stream = tu.stream && ws && tu.wide && Cp % (8 * VEC) == 0 && units >= 24L * tu.cus &&
+                            (MT * NT < tu.cus || (MT * NT <= tu.stream_max_tiles && units / (MT * NT) >= 96)) &&
                             tu.cus <= Y2_STREAM_FLAG_WORDS && (Y2_STREAM_FLAG_WORDS + (size_t)tu.cus * 128 * 128) * sizeof(float) <= ws_bytes;
         if (stream) {
             if (hipMemsetAsync(ws, 0, Y2_STREAM_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;   // flags only

@@ -5,6 +5,7 @@
 // contiguous NHWC channel axis; per-channel parameters stay in registers because every thread
 // keeps a fixed channel group while it strides over pixels.
 #include "common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 
 // ------------------------------------------------------------------------------------------
@@ -278,7 +279,8 @@ static int colsum_grid(long M, int C, int vec) {
     int tpr = C / vec, rpp = 256 / tpr;
     if (rpp < 1) rpp = 1;
     long g = (M + (long)rpp * 4 - 1) / ((long)rpp * 4);
-    if (g > 512) g = 512;       // 2 workgroups per CU; keeps the finalisation short
+    static const int cap = [] { const char *e = getenv("YOLO2_COLSUM_BLOCKS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+    if (g > cap) g = cap;       // default 1 workgroup per CU (measured best: 64..1024 swept); keeps the finalisation short (workspace contract: <= 1024)
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -413,11 +415,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T *__restrict_
                 part[1][j] += g;       // dbeta
             }
         };
-        for (; r + step < M; r += 2 * step) {              // 4 independent 16-byte loads in flight per lane
-            Vec16<T> y0 = ld16(Y + r * C + rm.cg * N), d0 = ld16(dA + r * ldda + rm.cg * N);
-            Vec16<T> y1 = ld16(Y + (r + step) * C + rm.cg * N), d1 = ld16(dA + (r + step) * ldda + rm.cg * N);
-            accum(y0, d0);
-            accum(y1, d1);
+        for (; r + 3 * step < M; r += 4 * step) {          // 8 independent 16-byte loads in flight per lane
+            Vec16<T> y[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                y[u] = ld16(Y + (r + u * step) * C + rm.cg * N);
+                d[u] = ld16(dA + (r + u * step) * ldda + rm.cg * N);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(y[u], d[u]);
         }
         for (; r < M; r += step) {
             Vec16<T> y = ld16(Y + r * C + rm.cg * N), d = ld16(dA + r * ldda + rm.cg * N);

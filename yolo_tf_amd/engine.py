@@ -155,7 +155,7 @@ class Engine(object):
             max_c = max(max_c, ldy)
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
-        self.conv_ws = torch.zeros(min(max(max_y, 1), 8 * 1024 * 1024), dtype=torch.float32, device=dev)
+        self.conv_ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device=dev)   # stream-K: flags + one f32 tile slot per CU
         self.ws = torch.zeros(1026 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
             # dY scratch ring: the filter gradient of layer L runs on a side stream concurrently with the data gradient
