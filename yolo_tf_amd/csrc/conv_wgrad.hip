@@ -19,6 +19,9 @@
 // Image borders / SAME padding / tails: the X lane whose shifted pixel falls outside the image, and every
 // lane beyond the pixel range or channel count, uses an out-of-range buffer offset -> the DMA writes 0.
 // 3-stage LDS ring with counted vmcnt + raw s_barrier as in conv_igemm.hip.
+// (A 256 x 128 tile with 64-pixel reduction tiles -- 64 x 64 per wave, 144 KiB ring, one workgroup per CU -- was
+// measured 1.5-1.9x slower on the 13x13 / 26x26 stages: the per-DMA-piece border bookkeeping and the single resident
+// workgroup outweigh the halved LDS traffic; profiles/r01_wgrad_big_tile.txt.)
 // Grid: x = (tap, c-tile, n-tile), y = pixel-range split; partial tiles are accumulated into the
 // zero-initialised f32 dW with hardware f32 atomics (lanes run along n -> coalesced).
 #include "common.h"
@@ -26,12 +29,12 @@
 
 #define Y2_OOB 0x80000000u
 
-template <typename T, int BC, int BNN, int VARIANT, int NW = 4>
+template <typename T, int BC, int BNN, int VARIANT, int NW = 4, int BKPv = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W,
     int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap) {
     constexpr int VEC = 16 / sizeof(T);
-    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;      // pixels per reduction tile
+    constexpr int BKP = BKPv ? BKPv : (sizeof(T) == 2 ? 32 : 16);      // pixels per reduction tile
     constexpr int XROWB = BC * sizeof(T), YROWB = BNN * sizeof(T);   // bytes per pixel row of a tile
     constexpr int XCH = XROWB / 16, YCH = YROWB / 16;  // 16-byte chunks per row
     constexpr int XRPI = 1024 / XROWB, YRPI = 1024 / YROWB;           // pixel rows per DMA instruction
@@ -43,9 +46,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     constexpr int TM = BC / WGM / 32, TN = BNN / 64;
     constexpr int KSTEP = sizeof(T) == 2 ? 16 : 2;
     static_assert(X_IT >= 1 && Y_IT >= 1, "tile too small for one DMA piece per wave");
-    // swizzle: chunk ^= 4 * ((row / rows_per_bank_line) % (row_bytes / 64)); identity for rows >= 512 B
-    constexpr int XRPL = XROWB >= 256 ? 1 : 256 / XROWB, XSWM = XROWB >= 512 ? 1 : XROWB / 64;
-    constexpr int YRPL = YROWB >= 256 ? 1 : 256 / YROWB, YSWM = YROWB >= 512 ? 1 : YROWB / 64;
+    // swizzle: chunk ^= 4 * ((row / rows_per_bank_line) % min(4, row_bytes / 64)): rows of >= 256 B all start on bank 0,
+    // so the 4 pixel rows of a transpose read are moved to 4 different bank quarters
+    constexpr int XRPL = XROWB >= 256 ? 1 : 256 / XROWB, XSWM = XROWB >= 256 ? 4 : XROWB / 64;
+    constexpr int YRPL = YROWB >= 256 ? 1 : 256 / YROWB, YSWM = YROWB >= 256 ? 4 : YROWB / 64;
 
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
 
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         const int n = n0 + chunk * VEC;
         y_voff[i] = (n < Cout && n < ldy) ? (unsigned)((long)(mbeg + r) * ldy + n) * (unsigned)sizeof(T) : Y2_OOB;
     }
+    const int adv_h = (BKP / W) % H, adv_w = BKP % W;     // adv_h + 1 <= H is needed for the single row wrap below
     const unsigned x_step = (unsigned)BKP * (unsigned)ldx * (unsigned)sizeof(T);
     const unsigned y_step = (unsigned)BKP * (unsigned)ldy * (unsigned)sizeof(T);
 
@@ -129,9 +134,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
             // advance this row slot by BKP pixels
             x_voff[i] += x_step;           // OOB + k*step stays >= 2^31 for every step taken (operands < 2^31 bytes)
             xm[i] += BKP;
-            xw[i] += BKP;
-            while (xw[i] - dw >= W) { xw[i] -= W; xh[i] += 1; }
-            while (xh[i] - dh >= H) xh[i] -= H;
+            xw[i] += adv_w;                 // BKP pixels further = adv_h rows + adv_w columns (branch-free: this runs per DMA piece)
+            xh[i] += adv_h;
+            const bool wrap = xw[i] - dw >= W;
+            xw[i] -= wrap ? W : 0;
+            xh[i] += wrap ? 1 : 0;
+            xh[i] -= (xh[i] - dh >= H) ? H : 0;
         }
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
@@ -253,13 +261,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
 static int g_wgrad_variant = 0;
 extern "C" void yolo2_debug_set_wgrad_variant(int v) { g_wgrad_variant = v; }
 
-template <typename T, int BC, int BNN>
+template <typename T, int BC, int BNN, int BKPv = 0>
 static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx,
                          int Cout, int ldy, int ksize, hipStream_t st) {
     const int M = B * H * W;
     const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
     const int tiles = ksize * ksize * CT * NT;
-    constexpr int BKP = sizeof(T) == 2 ? 32 : 16;
+    constexpr int BKP = BKPv ? BKPv : (sizeof(T) == 2 ? 32 : 16);
     // Pixel-range split (every block ends with one f32 atomic per output element, so fewer, longer blocks =
     // less atomic traffic; more blocks = more latency hiding).  Measured on the Darknet-19 shapes
     // (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
