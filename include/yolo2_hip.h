@@ -81,7 +81,9 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
 
 /* The same for every layer of a network in one launch.  `descs_device` is a DEVICE array of n descriptors
  * sorted by first_block; layer i owns blocks [first_block_i, first_block_{i+1}) and needs
- * ksize^2 * ceil(ldcin/32) * ceil(ldcout/32) of them; total_blocks = end of the last layer. */
+ * ksize^2 * ceil(ldcin/T) * ceil(ldcout/T) of them, T = YOLO2_FILTER_PREP_TILE; total_blocks = end of the last layer.
+ * ldcin, ldcout must be multiples of 8 and Ffwd/Fdgr 16-byte aligned. */
+#define YOLO2_FILTER_PREP_TILE 64
 typedef struct yolo2_filter_desc {
     const float *W;      /* HWIO f32 master weights */
     void *Ffwd;          /* [Cout][k*k*ldcin]  or NULL */

@@ -223,7 +223,7 @@ def test_filter_prep_batch_matches_per_layer(ops):
             ops.filter_prep(w, ef, ed, k, cin, ldcin, cout, ldcout, tdtype)
             d.W, d.Ffwd, d.Fdgr = w.data_ptr(), ff.data_ptr(), fd.data_ptr()
             d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, cin, ldcin, cout, ldcout, first
-            first += k * k * ((ldcin + 31) // 32) * ((ldcout + 31) // 32)
+            first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
             keep.append((w, ff, fd, ef, ed))
         descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
         ops.filter_prep_batch(descs, len(layers), first, tdtype)

@@ -88,14 +88,13 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
 
     // per-lane DMA descriptors
     unsigned x_voff[X_IT], y_voff[Y_IT];
-    int xh[X_IT], xw[X_IT], xm[X_IT];
+    int xh[X_IT], xw[X_IT];
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
         const int r = (wave * X_IT + i) * XRPI + lane / XCH;                 // pixel row inside the tile
         const int chunk = (lane % XCH) ^ (((r / XRPL) % XSWM) * 4);          // source-side swizzle
         const int c = c0 + chunk * VEC;
         const int m = mbeg + r;
-        xm[i] = m;
         const int rem = m % (H * W);
         xh[i] = rem / W + dh;                                                // shifted coordinates of this row's pixel
         xw[i] = rem % W + dw;
@@ -128,12 +127,12 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         unsigned char *Ys = Xs + XBYTES;
 #pragma unroll
         for (int i = 0; i < X_IT; ++i) {
-            const bool ok = xm[i] < mend && (unsigned)xh[i] < (unsigned)H && (unsigned)xw[i] < (unsigned)W;
+            // (rows past this block's pixel range need no test: their dY rows read as zero through rsrcY's limit)
+            const bool ok = (unsigned)xh[i] < (unsigned)H && (unsigned)xw[i] < (unsigned)W;
             const unsigned voff = ok ? x_voff[i] : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(Xs + (wave * X_IT + i) * 1024), 16, voff, 0, 0, 0);
             // advance this row slot by BKP pixels
             x_voff[i] += x_step;           // OOB + k*step stays >= 2^31 for every step taken (operands < 2^31 bytes)
-            xm[i] += BKP;
             xw[i] += adv_w;                 // BKP pixels further = adv_h rows + adv_w columns (branch-free: this runs per DMA piece)
             xh[i] += adv_h;
             const bool wrap = xw[i] - dw >= W;

@@ -76,50 +76,94 @@ extern "C" int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksi
 }
 
 // All layers in ONE launch (the per-layer calls were 43 launches of ~9 us each per training step): a device
-// table of descriptors; work unit u of a layer = one 32x32 (c, n) tile of one tap, handling BOTH layouts
-// from the same LDS tile (Ffwd needs the transpose, Fdgr is a re-strided copy).
+// table of descriptors; work unit u of a layer = one 64 x 64 (c, n) tile of one tap, handling BOTH layouts
+// from the same LDS tile (Ffwd needs the transpose, Fdgr is a re-strided copy).  16-byte loads and stores
+// (a 32 x 32 tile with 2-byte stores ran at 2.5 TB/s: 215 us per training step).
 template <typename T>
-__global__ void filter_prep_batch_kernel(const yolo2_filter_desc *__restrict__ descs, int n) {
-    __shared__ float tile[32][33];
+__device__ __forceinline__ void store8(T *dst, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x8 *>(dst) = o;
+    } else {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        reinterpret_cast<f32x4 *>(dst)[0] = a;
+        reinterpret_cast<f32x4 *>(dst)[1] = b;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void filter_prep_batch_kernel(const yolo2_filter_desc *__restrict__ descs, int n) {
+    constexpr int TS = YOLO2_FILTER_PREP_TILE;
+    __shared__ float tile[TS][TS + 1];
     int li = 0;
     while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].first_block) ++li;
     const yolo2_filter_desc d = descs[li];
     const int taps = d.ksize * d.ksize;
-    const int ldmax_c = d.ldcin, ldmax_n = d.ldcout;
-    const int ctiles = (ldmax_c + 31) / 32, ntiles = (ldmax_n + 31) / 32;
+    const int ctiles = (d.ldcin + TS - 1) / TS, ntiles = (d.ldcout + TS - 1) / TS;
     int u = blockIdx.x - d.first_block;
     const int ntile = u % ntiles; u /= ntiles;
     const int ctile = u % ctiles;
     const int tap = u / ctiles;
-    const int n0 = ntile * 32, c0 = ctile * 32;
-    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
-    for (int i = ty; i < 32; i += 8) {
-        int c = c0 + i, nn = n0 + tx;
-        tile[i][tx] = (c < d.cin && nn < d.cout) ? d.W[((long)tap * d.cin + c) * d.cout + nn] : 0.f;
+    const int n0 = ntile * TS, c0 = ctile * TS;
+    const int tid = threadIdx.x;
+    const float *Wt = d.W + (long)tap * d.cin * d.cout;
+    const bool vec_ok = (d.cout & 3) == 0 && (((uintptr_t)d.W) & 15) == 0;
+    {   // load: 16 lanes x float4 per row, 16 rows per pass
+        const int col = (tid & 15) * 4, r0 = tid >> 4;
+#pragma unroll
+        for (int p = 0; p < TS / 16; ++p) {
+            const int c = c0 + r0 + p * 16, nn = n0 + col;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < d.cin) {
+                if (vec_ok && nn + 3 < d.cout) {
+                    const f32x4 t = *reinterpret_cast<const f32x4 *>(Wt + (long)c * d.cout + nn);
+                    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nn + j < d.cout) v[j] = Wt[(long)c * d.cout + nn + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r0 + p * 16][col + j] = v[j];
+        }
     }
     __syncthreads();
     T *Ff = (T *)d.Ffwd, *Fd = (T *)d.Fdgr;
-    if (Ff) {
+    const int g8 = (tid & 7) * 8, rr = tid >> 3;       // 8 lanes x 8 elements per row, 32 rows per pass
+    if (Ff) {       // rows n, c contiguous: transpose through LDS ((c + n) % 64 distinct per pass: conflict-free)
         const long Kf = (long)taps * d.ldcin;
-        for (int i = ty; i < 32; i += 8) {
-            int nn = n0 + i, c = c0 + tx;
-            if (nn < d.cout && c < d.ldcin) Ff[nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps)] = (T)tile[tx][i];
+#pragma unroll
+        for (int p = 0; p < TS / 32; ++p) {
+            const int nl = rr + p * 32, nn = n0 + nl, c = c0 + g8;
+            if (nn < d.cout && c < d.ldcin) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[g8 + j][nl];
+                store8<T>(Ff + nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps), v);
+            }
         }
     }
-    if (Fd) {
+    if (Fd) {       // rows c, n contiguous, taps flipped
         const long Kd = (long)taps * d.ldcout;
-        const int tp = taps - 1 - tap;            // flipped tap
-        for (int i = ty; i < 32; i += 8) {
-            int c = c0 + i, nn = n0 + tx;
-            if (c < d.cin && nn < d.ldcout) Fd[c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps)] = (T)tile[i][tx];
+        const int tp = taps - 1 - tap;
+#pragma unroll
+        for (int p = 0; p < TS / 32; ++p) {
+            const int cl = rr + p * 32, c = c0 + cl, nn = n0 + g8;
+            if (c < d.cin && nn < d.ldcout) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[cl][g8 + j];
+                store8<T>(Fd + c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps), v);
+            }
         }
     }
 }
 
 extern "C" int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype, void *stream) {
     Y2_CHECK_ARG(descs_device && n > 0 && total_blocks > 0);
-    dim3 block(32, 8);
-    Y2_DISPATCH_DTYPE(dtype, filter_prep_batch_kernel<T><<<total_blocks, block, 0, (hipStream_t)stream>>>(descs_device, n));
+    Y2_DISPATCH_DTYPE(dtype, filter_prep_batch_kernel<T><<<total_blocks, 256, 0, (hipStream_t)stream>>>(descs_device, n));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -724,20 +768,36 @@ extern "C" int yolo2_add_inplace(void *dst, const void *src, long n, int dtype, 
 // ------------------------------------------------------------------------------------------
 // image prep (tf.image.per_image_standardization, train.py:103; utils/preprocess.py:23-25)
 // ------------------------------------------------------------------------------------------
-__global__ void image_sums_kernel(const float *__restrict__ img, double *__restrict__ ws, long n_per_image) {
+__global__ __launch_bounds__(256) void image_sums_kernel(const float *__restrict__ img, double *__restrict__ ws, long n_per_image) {
     const int b = blockIdx.y;
     const float *p = img + (long)b * n_per_image;
-    double s = 0.0, q = 0.0;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_per_image; i += (long)gridDim.x * blockDim.x) {
-        double v = (double)p[i];
-        s += v;
-        q += v * v;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if ((((uintptr_t)p) & 15) == 0) {         // 16-byte loads, 4 independent f64 chains per quantity
+        const long n4 = n_per_image >> 2;
+        const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p);
+        for (; i < n4; i += stride) {
+            const f32x4 v = p4[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double d = (double)v[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
+        }
+        i = (n4 << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x;
     }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
+    for (; i < n_per_image; i += stride) {
+        const double d = (double)p[i];
+        s[0] += d;
+        q[0] += d * d;
+    }
+    const double st = wave_sum_d((s[0] + s[1]) + (s[2] + s[3]));
+    const double qt = wave_sum_d((q[0] + q[1]) + (q[2] + q[3]));
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(ws + 2 * b, s);
-        atomicAdd(ws + 2 * b + 1, q);
+        atomicAdd(ws + 2 * b, st);
+        atomicAdd(ws + 2 * b + 1, qt);
     }
 }
 template <typename T>
@@ -770,7 +830,7 @@ extern "C" int yolo2_image_prep(const float *img, void *out, double *ws, int B, 
     if (mode == 0) {
         Y2_CHECK_ARG(ws);
         if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, st) != hipSuccess) { yolo2_set_error("image_prep: memset failed"); return YOLO2_E_LAUNCH; }
-        dim3 grid(64, B);
+        dim3 grid(B >= 64 ? 8 : B >= 8 ? 32 : 128, B);
         image_sums_kernel<<<grid, 256, 0, st>>>(img, ws, (long)HW * 3);
     }
     Y2_DISPATCH_DTYPE(dtype, image_apply_kernel<T><<<ew_grid((long)B * HW), 256, 0, st>>>(img, (T *)out, ws, B, HW, mode));

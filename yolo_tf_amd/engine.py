@@ -196,7 +196,7 @@ class Engine(object):
                 d.Ffwd = st['Ffwd'].data_ptr()
                 d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
                 d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
-                first += k * k * ((ldcin + 31) // 32) * ((ldcout + 31) // 32)
+                first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
             raw = bytes(arr)
             self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
             self._fdesc_n, self._fdesc_blocks = len(convs), first
