@@ -93,6 +93,21 @@ typedef struct yolo2_filter_desc {
 int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype,
                             void *stream);
 
+/* Forward convolution of a batch-normalised layer (no bias): as yolo2_conv2d_ws, and the per-channel shifted sums
+ *   sum_m (y[m,n] - shift[n]),  sum_m (y[m,n] - shift[n])^2        (y = the stored, rounded output)
+ * are accumulated into bn_part, f32 [2][YOLO2_BN_PART_ROWS][Nf], by the convolution's own epilogue (f32 atomics on
+ * row (tile % ROWS)); yolo2_bn_finalize turns them into the batch moments.  This replaces the separate statistics
+ * pass over y of slim.batch_norm's tf.nn.moments (model/yolo2/inference.py:62-66).  bn_part must be all zero on entry
+ * (yolo2_bn_finalize leaves it zero); shift is any per-channel estimate of the mean (the engine passes
+ * moving_mean): it only conditions the single-pass variance.  Requires ldo == Nf. */
+#define YOLO2_BN_PART_ROWS 256
+int yolo2_conv2d_bn(const void *P, const void *F, void *O, float *ws, size_t ws_bytes, int B, int H, int W, int Cp, int ldp,
+                    int Nf, int ldo, int ksize, const float *shift, float *bn_part, int dtype, void *stream);
+/* mean[c] = shift[c] + S1/M, var[c] = S2/M - (S1/M)^2 (biased, f64), optional moving-average update as
+ * yolo2_bn_stats_ema (moving_* may both be NULL); zeroes bn_part. */
+int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int C, float *mean, float *var, float *moving_mean,
+                      float *moving_var, double decay, void *stream);
+
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
 /* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1025*C doubles of scratch

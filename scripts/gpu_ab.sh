@@ -9,6 +9,6 @@ while IFS= read -r cfg; do
     echo "$cfg rep$rep: $v" | tee -a gpurun_out/ab.log
   done
 done <<CFG
-YOLO2_IGEMM_BM256=1
-YOLO2_IGEMM_BM256=0
+YOLO2_FUSE_BN_STATS=1
+YOLO2_FUSE_BN_STATS=0
 CFG

@@ -145,6 +145,50 @@ def test_conv_forward_ksliced(ops, shape, mode):
     assert_close(y[..., :Cout], ref, F32_RTOL if mode == 'f32' else BF16_RTOL, 'conv fwd k-sliced %s %s' % (shape, mode))
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 26, 26, 64, 160, 3),      # direct tiles, M tail
+                                   (1, 64, 96, 3, 32, 3),        # first-layer direct kernel -> statistics by the column-sum fallback
+                                   (2, 13, 13, 512, 256, 3),     # K-sliced grid -> fallback
+                                   (8, 13, 13, 1024, 504, 3),    # stream-K: owners hold the finished tiles
+                                   (3, 20, 20, 32, 64, 3),       # 64-filter tile
+                                   (2, 13, 13, 128, 256, 1)])
+def test_conv_bn_fused_statistics(ops, shape, mode):
+    """yolo2_conv2d_bn + yolo2_bn_finalize: same output as yolo2_conv2d_ws, batch moments of the STORED output (tf.nn.moments
+    semantics, biased variance), moving averages updated with decay 0.999, partial buffer left zero."""
+    B, H, W, Cin, Cout, k = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(sum(shape) + 7)
+    x = rng.randn(B, H, W, Cin).astype(np.float32)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32) + 0.02
+    ldx = ops.pad8(Cin)
+    F = torch.zeros(Cout * k * k * ldx, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, ldx, Cout, Cout, tdtype)
+    xd = dev(pad_channels(x, ldx), tdtype)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    M = B * H * W
+    y_ref = torch.zeros(M * Cout, dtype=tdtype, device='cuda')
+    ops.conv2d_ws(xd, F, None, y_ref, ws, B, H, W, ldx, ldx, Cout, Cout, k)
+    y = torch.zeros(M * Cout, dtype=tdtype, device='cuda')
+    part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
+    mm0 = (rng.randn(Cout) * 0.1).astype(np.float32)
+    mv0 = (rng.rand(Cout) + 0.5).astype(np.float32)
+    mm, mv = dev(mm0), dev(mv0)
+    mean, var = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+    ops.conv2d_bn(xd, F, y, ws, B, H, W, ldx, ldx, Cout, Cout, k, mm, part)
+    ops.bn_finalize(part, mm, M, Cout, mean, var, mm, mv, 0.999)
+    torch.cuda.synchronize()
+    # (K-sliced grids accumulate with f32 atomics: the summation order, hence the last bit, varies between launches)
+    assert_close(host(y), host(y_ref), 1e-6 if mode == 'f32' else 8e-3, 'conv_bn output %s %s' % (shape, mode))
+    assert float(part.abs().max()) == 0.0
+    yh = host(y).astype(np.float64).reshape(M, Cout)
+    m_ref, v_ref = yh.mean(0), yh.var(0)
+    scale = np.sqrt(v_ref).max()
+    assert np.abs(host(mean) - m_ref).max() <= 2e-5 * scale + 1e-6
+    assert np.abs(host(var) - v_ref).max() <= 1e-4 * v_ref.max()
+    np.testing.assert_allclose(host(mm), mm0 - (mm0 - host(mean)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
+
+
 WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]
 
 

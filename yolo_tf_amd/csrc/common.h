@@ -19,6 +19,10 @@ bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize);
 int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st);
 int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int dtype, hipStream_t st);
 
+// batch-norm partial sums produced by the convolution epilogue: [2][Y2_BN_PART_ROWS][C] f32 (elementwise.hip finalises)
+#define Y2_BN_PART_ROWS YOLO2_BN_PART_ROWS
+int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st);
+
 #define Y2_CHECK_ARG(cond)                                                          \
     do {                                                                            \
         if (!(cond)) {                                                              \

@@ -57,7 +57,8 @@ template <> struct Mma<float> {
 template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4, int BMv = 128>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
-    T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap) {
+    T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part) {
     constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
@@ -304,11 +305,17 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         }
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // With bn_part != NULL (forward of a batch-normalised layer) the tile also contributes its columns' shifted sums
+    // sum(y - shift), sum((y - shift)^2) of the STORED (rounded) outputs to one of Y2_BN_PART_ROWS partial rows: the
+    // statistics pass over y (a full re-read of every activation, 21 launches per step) is gone.
+    const bool stats = SPLITK != 1 && bn_part != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (n >= Nf) continue;
         const float bv = (SPLITK != 1 && bias) ? bias[n] : 0.f;
+        const float sh = stats ? bn_shift[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
@@ -317,8 +324,23 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m < M) {
                     if (SPLITK == 1) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
-                    else O[(long)m * ldo + n] = (T)(acc[i][j][r] + bv);
+                    else {
+                        const T o = (T)(acc[i][j][r] + bv);
+                        O[(long)m * ldo + n] = o;
+                        const float d = (float)o - sh;
+                        s1 += d;
+                        s2 += d * d;
+                    }
                 }
+            }
+        }
+        if (stats) {      // lanes l and l^32 hold the same column (both pass the n < Nf test together)
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 32) {
+                const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
+                unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
             }
         }
     }
@@ -372,7 +394,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
     conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
-        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap)
+        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
 #define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
@@ -393,7 +415,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
-                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st) {
+                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
@@ -442,6 +464,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             if (ksize == 3) Y2_IGEMM(128, 2, 3, 3, 2, false, 8, 8, grid);
             else Y2_IGEMM(128, 2, 3, 1, 2, false, 8, 8, grid);
         } else if (ks > 1) {
+            *stats_done = false;        // partial tiles meet only in the finishing kernel
             if (hipMemsetAsync(ws, 0, (size_t)M * Nf * sizeof(float), st) != hipSuccess) return 1;
             dim3 grid(MT * NT, ks);
             Y2_IGEMM_KS_CT(128, 2, 3, 1, 4, grid);     // 4-wave workgroups: 3 per CU, measured best with slicing
@@ -465,7 +488,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
 }
 
 static int conv2d_impl(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H,
-                       int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn) {
+                       int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn,
+                       const float *bn_shift = nullptr, float *bn_part = nullptr) {
     if (!(P && F && O) || !(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0) || !(ksize == 1 || ksize == 3) || !(ldp >= Cp && ldo >= Nf)) {
         yolo2_set_error("%s: argument check failed: pointers / extents / ksize / strides", fn);
         return YOLO2_E_ARG;
@@ -485,17 +509,31 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream);
         Y2_CHECK_LAUNCH();
+        if (bn_part) return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream);
         return YOLO2_OK;
     }
-    Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream));
+    bool stats_done = true;
+    Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
+                                                 bn_shift, bn_part, &stats_done));
     if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
     Y2_CHECK_LAUNCH();
+    if (bn_part && !stats_done)       // K-sliced path: statistics from a pass over the finished output
+        return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream);
     return YOLO2_OK;
 }
 
 extern "C" int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O, int B, int H,
                             int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream) {
     return conv2d_impl(P, F, bias, O, nullptr, 0, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d");
+}
+
+extern "C" int yolo2_conv2d_bn(const void *P, const void *F, void *O, float *ws, size_t ws_bytes, int B, int H, int W, int Cp, int ldp,
+                               int Nf, int ldo, int ksize, const float *shift, float *bn_part, int dtype, void *stream) {
+    if (!shift || !bn_part || ldo != Nf) {
+        yolo2_set_error("yolo2_conv2d_bn: argument check failed: shift / bn_part NULL or ldo != Nf");
+        return YOLO2_E_ARG;
+    }
+    return conv2d_impl(P, F, nullptr, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_bn", shift, bn_part);
 }
 
 extern "C" int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B,

@@ -214,13 +214,17 @@ __device__ __forceinline__ void block_colsum_store(const float (&part)[K][N], co
 // instead of mean^2 (plain E[x^2]-mean^2 loses the variance when |mean| >> std, e.g. few samples per
 // channel).  Block 0 also stores s as a third row of the partial buffer.   K = 1: plain column sum.
 template <typename T, int K>
-__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, float *__restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, int ld, long M, int C, float *__restrict__ part,
+                                                     const float *__restrict__ shift_in = nullptr, int nb_rows = 0) {
     constexpr int N = Vec16<T>::N;
     RowMap rm(C, N);
     float acc[K][N], sh[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) sh[j] = 0.f;
-    if (K == 2 && rm.active) {
+    if (K == 2 && rm.active && shift_in) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) sh[j] = shift_in[rm.cg * N + j];
+    } else if (K == 2 && rm.active) {
         Vec16<T> v0 = ld16(X + rm.cg * N);
 #pragma unroll
         for (int j = 0; j < N; ++j) sh[j] = v0.get(j);
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ X, in
             }
         }
     }
-    block_colsum_store<N, K>(acc, rm, C, part, gridDim.x);
+    block_colsum_store<N, K>(acc, rm, C, part, nb_rows ? nb_rows : gridDim.x);
 }
 
 // FIN 0: (sum x, sum x^2) -> mean, biased var;  FIN 1: two sums -> two f32 outputs;  FIN 2: one sum -> o0
@@ -327,6 +331,77 @@ static int colsum_grid(long M, int C, int vec) {
     if (g > cap) g = cap;       // default 1 workgroup per CU (measured best: 64..1024 swept); keeps the finalisation short (workspace contract: <= 1024)
     if (g < 1) g = 1;
     return (int)g;
+}
+
+// Fallback producer of the convolution epilogue's partial format ([2][Y2_BN_PART_ROWS][C], zero on entry): used for the
+// layers whose convolution cannot produce the sums itself (first-layer direct kernel, K-sliced grids).
+int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st) {
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ld == C);
+    int nb = colsum_grid(M, C, vec);
+    if (nb > Y2_BN_PART_ROWS) nb = Y2_BN_PART_ROWS;
+    Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 2><<<nb, 256, 0, st>>>((const T *)Y, ld, M, C, part, shift, Y2_BN_PART_ROWS));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// partial rows -> batch mean / biased variance (+ moving-average update), and the rows are zeroed again for the next step
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float *__restrict__ part, const float *__restrict__ shift, int C, long M,
+                                                          float *__restrict__ mean_out, float *__restrict__ var_out,
+                                                          float *__restrict__ mm, float *__restrict__ mv, float omd) {
+    constexpr int NB = Y2_BN_PART_ROWS;
+    __shared__ double red[2][16][17];
+    const int col = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (c < C) {
+            float *p = part + (long)k * NB * C + c;
+            float v[NB / 16];
+#pragma unroll
+            for (int u = 0; u < NB / 16; ++u) v[u] = p[(long)(rg + 16 * u) * C];
+#pragma unroll
+            for (int u = 0; u < NB / 16; ++u) p[(long)(rg + 16 * u) * C] = 0.f;
+#pragma unroll
+            for (int u = 0; u < NB / 16; u += 4) {
+                s0 += (double)v[u];
+                s1 += (double)v[u + 1];
+                s2 += (double)v[u + 2];
+                s3 += (double)v[u + 3];
+            }
+        }
+        red[k][rg][col] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        double t[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a += red[k][r][col];
+            t[k] = a;
+        }
+        const double dm = t[0] / (double)M;
+        const double var = t[1] / (double)M - dm * dm;
+        const double mean = (double)shift[c] + dm;
+        const float fm = (float)mean, fv = (float)(var > 0.0 ? var : 0.0);
+        mean_out[c] = fm;
+        var_out[c] = fv;
+        if (mm) {
+            mm[c] = mm[c] - (mm[c] - fm) * omd;
+            mv[c] = mv[c] - (mv[c] - fv) * omd;
+        }
+    }
+}
+extern "C" int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int C, float *mean, float *var, float *moving_mean,
+                                 float *moving_var, double decay, void *stream) {
+    Y2_CHECK_ARG(bn_part && shift && mean && var && M > 0 && C > 0);
+    Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
+    bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(bn_part, shift, C, M, mean, var, moving_mean, moving_var, (float)(1.0 - decay));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
 }
 
 static int bn_stats_impl(const void *Y, float *mean, float *var, float *mm, float *mv, double decay, double *ws, long M, int C, int dtype, void *stream);

@@ -155,6 +155,8 @@ class Engine(object):
             max_c = max(max_c, ldy)
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
+        self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
+        self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
         self.conv_ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device=dev)   # stream-K: flags + one f32 tile slot per CU
         self.ws = torch.zeros(1026 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
@@ -168,14 +170,17 @@ class Engine(object):
         self.img = None
 
     # ---------------------------------------------------------------- helpers
-    def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k):
+    def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k, bn_shift=None):
         """yolo2_conv2d launch; when a timer is attached, launches that take the 128-wide filter tile
         (Nf > 64: the kernel that carries ~2/3 of the training FLOPs) are bracketed by HIP events.
         ``real_k`` = unpadded reduction length, for the algorithmic FLOP count."""
         t = self.kernel_timer if Nf > 64 else None
         if t is not None:
             t.start(2.0 * self.B * H * W * Nf * real_k, self._phase)
-        ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
+        if bn_shift is not None:     # training forward of a batch-normalised layer: statistics from the conv epilogue
+            ops.conv2d_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, bn_shift, self.bn_part)
+        else:
+            ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
         if t is not None:
             t.stop()
 
@@ -224,14 +229,20 @@ class Engine(object):
                 M = B * out.h * out.w
                 if op['bn']:
                     yb, ldy = self.act[op['y']]
-                    self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'])
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
-                    if self.training:
-                        ops.bn_stats_ema(yb, st['mean'], st['var'], self.var[op['moving_mean'].name], self.var[op['moving_variance'].name],
-                                         BN_DECAY, self.ws, M, op['cout'])
+                    mmean, mvar = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
+                    fused = self.training and self.fuse_bn_stats and ldy == op['cout']
+                    self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'],
+                               bn_shift=mmean if fused else None)
+                    if fused:
+                        # batch moments from the partial sums the convolution left behind (shift = the moving mean)
+                        ops.bn_finalize(self.bn_part, mmean, M, op['cout'], st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                        mean, var = st['mean'], st['var']
+                    elif self.training:
+                        ops.bn_stats_ema(yb, st['mean'], st['var'], mmean, mvar, BN_DECAY, self.ws, M, op['cout'])
                         mean, var = st['mean'], st['var']
                     else:
-                        mean, var = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
+                        mean, var = mmean, mvar
                     ob, ldo = self.act[out]
                     ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
                 else:

@@ -25,6 +25,15 @@ def conv2d_ws(P, F, bias, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize):
          dtype_code(P.dtype), _stream())
 
 
+def conv2d_bn(P, F, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, shift, bn_part):
+    call('yolo2_conv2d_bn', ptr(P), ptr(F), ptr(O), ptr(ws), ws.numel() * ws.element_size(), B, H, W, Cp, ldp, Nf, ldo, ksize,
+         ptr(shift), ptr(bn_part), dtype_code(P.dtype), _stream())
+
+
+def bn_finalize(bn_part, shift, M, C, mean, var, mm, mv, decay):
+    call('yolo2_bn_finalize', ptr(bn_part), ptr(shift), M, C, ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, _stream())
+
+
 def conv2d_wgrad(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize):
     call('yolo2_conv2d_wgrad', ptr(X), ptr(dY), ptr(dW), B, H, W, Cin, ldx, Cout, ldy, ksize, dtype_code(X.dtype), _stream())
 
