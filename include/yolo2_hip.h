@@ -55,7 +55,8 @@ int yolo2_conv2d(const void *P, const void *F, const float *bias, void *O,
  * accumulated in `ws` (>= B*H*W*Nf floats for slicing to be considered; smaller = no slicing) and a
  * finishing kernel writes O.  Grids below one tile per CU with a long reduction instead run "stream-K": one
  * workgroup per CU, equal contiguous shares of the flat (tile, K step) space, partial tiles parked in `ws`
- * (needs >= (1024 + CUs*128*128) floats = 16.8 MB on MI355X) and fixed up inside the same launch.
+ * (needs >= CUs*256*128 floats = 33.6 MB on MI355X for the 256x128 tile, half for 128x128) and fixed up inside the same
+ * launch through library-owned hand-off flags.
  * `ws` may hold anything on entry.  Results agree with yolo2_conv2d to f32 rounding of the partial sums. */
 int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws,
                     size_t ws_bytes, int B, int H, int W, int Cp, int ldp, int Nf, int ldo,

@@ -147,7 +147,7 @@ def test_conv_forward_ksliced(ops, shape, mode):
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 26, 26, 64, 160, 3),      # direct tiles, M tail
-                                   (1, 64, 96, 3, 32, 3),        # first-layer direct kernel -> statistics by the column-sum fallback
+                                   (1, 64, 96, 3, 32, 3),        # first-layer direct kernel (its own statistics epilogue)
                                    (2, 13, 13, 512, 256, 3),     # K-sliced grid -> fallback
                                    (8, 13, 13, 1024, 504, 3),    # stream-K: owners hold the finished tiles
                                    (3, 20, 20, 32, 64, 3),       # 64-filter tile

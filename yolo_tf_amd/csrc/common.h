@@ -16,7 +16,8 @@ void yolo2_set_error(const char *fmt, ...);
 
 // first-layer direct convolution (conv_first.hip), used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches
 bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize);
-int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st);
+int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st,
+                       const float *bn_shift = nullptr, float *bn_part = nullptr);
 int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int dtype, hipStream_t st);
 
 // batch-norm partial sums produced by the convolution epilogue: [2][Y2_BN_PART_ROWS][C] f32 (elementwise.hip finalises)

@@ -53,7 +53,8 @@ __device__ __forceinline__ void stage_halo(const __amdgpu_buffer_rsrc_t &rsrcX, 
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ F, T *__restrict__ Y,
-                                                             int B, int H, int W, int units) {
+                                                             int B, int H, int W, int units, const float *__restrict__ bn_shift,
+                                                             float *__restrict__ bn_part) {
     constexpr int SLOT = First<T>::HALO, PXB = First<T>::PXB;
     constexpr int LOADS = 3 * First<T>::HPIECES;
     constexpr int KS = sizeof(T) == 2 ? 5 : 36;              // MFMA steps over the 72 (80) reduction values
@@ -80,6 +81,10 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict
             bf[s] = F[n * 72 + k];
         }
     }
+
+    // optional batch-norm partial sums of the stored outputs (same contract as conv_igemm.hip's epilogue)
+    const float sh = bn_part ? bn_shift[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 
     const int stride = gridDim.x * 4;
     int u = blockIdx.x * 4 + wave;
@@ -122,10 +127,25 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int px = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (w0 + px < W) out[(long)px * 32] = (T)acc[r];
+            if (w0 + px < W) {
+                const T o = (T)acc[r];
+                out[(long)px * 32] = o;
+                const float d = (float)o - sh;
+                s1 += d;
+                s2 += d * d;
+            }
         }
         b = nb; h = nh; w0 = nw0;
         st ^= 1;
+    }
+    if (bn_part) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32) {
+            const int slot = (blockIdx.x * 4 + wave) & (Y2_BN_PART_ROWS - 1);
+            unsafeAtomicAdd(bn_part + slot * 32 + n, s1);
+            unsafeAtomicAdd(bn_part + (Y2_BN_PART_ROWS + slot) * 32 + n, s2);
+        }
     }
 }
 
@@ -266,14 +286,14 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T *__restri
 // ---------------------------------------------------------------------------------------------------
 bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize) { return ksize == 3 && Cp == 8 && ldp == 8 && Nf == 32 && ldo == 32; }
 
-int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st) {
+int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st, const float *bn_shift, float *bn_part) {
     const int units = B * H * ((W + 31) / 32);
     const int grid = units / 4 + 1 < 2048 ? units / 4 + 1 : 2048;
     // the forward filter operand is [32][9*8]: the generic layout with ldcin = 8
     if (dtype == YOLO2_BF16)
-        conv_first_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)O, B, H, W, units);
+        conv_first_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)O, B, H, W, units, bn_shift, bn_part);
     else
-        conv_first_fwd_kernel<float><<<grid, 256, 0, st>>>((const float *)P, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)F, (float *)O, B, H, W, units);
+        conv_first_fwd_kernel<float><<<grid, 256, 0, st>>>((const float *)P, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)F, (float *)O, B, H, W, units, bn_shift, bn_part);
     return 0;
 }
 

@@ -48,7 +48,7 @@ template <> struct Mma<float> {
     }
 };
 
-#define Y2_STREAM_FLAG_WORDS 1024     // stream-K workspace: one flag word per workgroup, then one f32 tile slot each
+#define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
 // DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
@@ -58,7 +58,7 @@ template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAI
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags) {
     constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
@@ -264,8 +264,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         // and published through a flag, before the workgroup can wait for anything -- so owners only ever wait for
         // work that is never itself blocked.  The owner adds the parked parts of the workgroups after it and writes
         // the finished tile (+ bias) directly.
-        unsigned *flags = reinterpret_cast<unsigned *>(Oacc);
-        float *slots = Oacc + Y2_STREAM_FLAG_WORDS;
+        unsigned *flags = sk_flags;       // library-owned, all zero between launches (each flag is cleared by its consumer)
+        float *slots = Oacc;
         constexpr int SLOT = BM * BN;
         if (kt_beg > 0) {
             float *mine = slots + (size_t)wx * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
@@ -291,6 +291,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             for (int p = wx + 1; covered < tile_end; ++p) {
                 if (tid == 0) {
                     while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exactly one consumer per flag
                 }
                 __syncthreads();
                 const float *theirs = slots + (size_t)p * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
@@ -380,6 +381,25 @@ static const Tune &tune() {   // tuning knobs (defaults = measured best); env ov
     }();
     return t;
 }
+// Stream-K hand-off flags: Y2_STREAM_FLAG_SETS sets of Y2_STREAM_FLAG_WORDS words per device, allocated and zeroed once; a
+// launch takes the next set round-robin (launches on different streams may overlap) and leaves it zero (every flag is
+// cleared by the one workgroup that waits for it), so no per-launch memset node is needed (16 of them cost 83 us a step).
+#define Y2_STREAM_FLAG_SETS 8
+static unsigned *stream_flags() {
+    static unsigned *pool[64] = {nullptr};
+    static unsigned counter[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pool[dev]) {
+        unsigned *p = nullptr;
+        const size_t bytes = (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_WORDS * sizeof(unsigned);
+        if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
+        pool[dev] = p;
+    }
+    return pool[dev] + (size_t)(counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_WORDS;
+}
+
 // number of K slices: when the M x N tile grid alone cannot fill 256 CUs with ~2-3 resident workgroups
 // each, slice K so that it does, keeping >= 8 K tiles per slice
 static int choose_ksplit(int tiles, int nk, int target) {
@@ -394,7 +414,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
     conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
-        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part)
+        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
 #define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
@@ -424,6 +444,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     const unsigned p_bytes = (unsigned)((size_t)M * ldp * sizeof(T));
     const unsigned f_bytes = (unsigned)((size_t)Nf * ksize * ksize * Cp * sizeof(T));
     const bool ctail = (Cp % BK) != 0;
+    unsigned *sk_flags = nullptr;
     // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
     const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
     const int MT2 = cdiv(M, 256), NT2 = cdiv(Nf, 128);
@@ -433,9 +454,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     // (profiles/r01_igemm_bm256.txt): +23 % on the 3072-channel layer; shorter reductions, fuller grids and grids under
     // 64 tiles (each tile cut into > 4 parts: the owner's serial fix-up) lose.
     if (Nf > 64 && tu.bm256 && ws && tu.stream && nk_wide >= 128 && MT2 * NT2 >= 64 && MT2 * NT2 <= 3 * tu.cus && tu.cus <= Y2_STREAM_FLAG_WORDS &&
-        (Y2_STREAM_FLAG_WORDS + (size_t)tu.cus * 256 * 128) * sizeof(float) <= ws_bytes) {
+        (size_t)tu.cus * 256 * 128 * sizeof(float) <= ws_bytes && (sk_flags = stream_flags()) != nullptr) {
         const int NT = NT2;
-        if (hipMemsetAsync(ws, 0, Y2_STREAM_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;   // flags only
         dim3 grid(tu.cus);
         if (ksize == 3) Y2_IGEMM_BM(256, 128, 2, 3, 3, 2, false, 8, 8, grid);
         else Y2_IGEMM_BM(256, 128, 2, 3, 1, 2, false, 8, 8, grid);
@@ -457,9 +477,9 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         const long units = (long)MT * NT * ksize * ksize * (Cp / (8 * VEC));
         const bool stream = tu.stream && ws && tu.wide && Cp % (8 * VEC) == 0 && units >= 24L * tu.cus &&
                             (MT * NT < tu.cus || (MT * NT <= tu.stream_max_tiles && units / (MT * NT) >= 96)) &&
-                            tu.cus <= Y2_STREAM_FLAG_WORDS && (Y2_STREAM_FLAG_WORDS + (size_t)tu.cus * 128 * 128) * sizeof(float) <= ws_bytes;
+                            tu.cus <= Y2_STREAM_FLAG_WORDS && (size_t)tu.cus * 128 * 128 * sizeof(float) <= ws_bytes &&
+                            (sk_flags = stream_flags()) != nullptr;
         if (stream) {
-            if (hipMemsetAsync(ws, 0, Y2_STREAM_FLAG_WORDS * sizeof(unsigned), st) != hipSuccess) return 1;   // flags only
             dim3 grid(tu.cus);
             if (ksize == 3) Y2_IGEMM(128, 2, 3, 3, 2, false, 8, 8, grid);
             else Y2_IGEMM(128, 2, 3, 1, 2, false, 8, 8, grid);
@@ -507,9 +527,8 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
     if (first_direct && !bias && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
-        y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream);
+        y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
         Y2_CHECK_LAUNCH();
-        if (bn_part) return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream);
         return YOLO2_OK;
     }
     bool stats_done = true;
