@@ -1,9 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 : > gpurun_out/tune.log
-timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -3 | tee -a gpurun_out/tune.log
-YOLO2_WGRAD_BIG=128 timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -3 | tee -a gpurun_out/tune.log
-for cfg in "YOLO2_WGRAD_BIG=0" "YOLO2_WGRAD_BIG=256 YOLO2_WGRAD_BIG_BLOCKS=256" "YOLO2_WGRAD_BIG=256 YOLO2_WGRAD_BIG_BLOCKS=512"; do
+YOLO2_WGRAD_BKP64=1 timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -3 | tee -a gpurun_out/tune.log
+YOLO2_WGRAD_BKP64=2 timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -3 | tee -a gpurun_out/tune.log
+for cfg in "YOLO2_WGRAD_BKP64=0" "YOLO2_WGRAD_BKP64=1" "YOLO2_WGRAD_BKP64=2" "YOLO2_WGRAD_BKP64=1 YOLO2_WGRAD_BLOCKS=256" "YOLO2_WGRAD_BKP64=2 YOLO2_WGRAD_BLOCKS=768"; do
   env $cfg python scripts/conv_bench.py "$cfg" 2>/dev/null | grep -v amdgpu.ids >> gpurun_out/tune.log
 done
 cat gpurun_out/tune.log
