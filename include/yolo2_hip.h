@@ -138,6 +138,21 @@ int yolo2_bn_leaky_bwd_apply(const void *dA, int ldda, const void *Y, const floa
                              const float *dgamma, const float *dbeta, void *dY, long M, int C,
                              float eps, float alpha, int dtype, void *stream);
 
+/* ---- BN + leaky + 2x2/2 max pool fused (layers whose only consumer is the pool: model/yolo2/inference.py:70-95,
+ * `net = slim.layers.max_pool2d(net)` right after a conv): the full-resolution activation and its gradient never reach
+ * HBM.  P[b,oh,ow,c] = max over the window of leaky(bn(Y)) rounded to dtype; idx (may be NULL for inference) receives
+ * one byte per pooled element: the window position 0..3 (row-major) of the FIRST maximum, which is where
+ * tf.nn.max_pool's gradient goes.  The backward pair equals yolo2_maxpool_bwd followed by yolo2_bn_leaky_bwd_*. */
+int yolo2_bn_leaky_pool(const void *Y, const float *mean, const float *var, const float *gamma, const float *beta, void *P,
+                        unsigned char *idx, int B, int H, int W, int C, int ldp, float eps, float alpha, int dtype, void *stream);
+int yolo2_bn_leaky_pool_bwd_reduce(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean,
+                                   const float *var, const float *gamma, const float *beta, float *dgamma, float *dbeta,
+                                   double *ws, int B, int H, int W, int C, float eps, float alpha, int dtype, void *stream);
+int yolo2_bn_leaky_pool_bwd_apply(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean,
+                                  const float *var, const float *gamma, const float *beta, const float *dgamma,
+                                  const float *dbeta, void *dY, int B, int H, int W, int C, float eps, float alpha,
+                                  int dtype, void *stream);
+
 /* ---- max pool 2x2, SAME: slim.layers.max_pool2d, model/yolo2/inference.py:38,42,74,83,96 ------
  * stride 2 (H,W even) or stride 1 (pads bottom/right; tiny model).  Backward routes to the
  * first maximum in row-major window order. */

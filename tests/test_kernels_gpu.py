@@ -277,6 +277,56 @@ def test_filter_prep_batch_matches_per_layer(ops):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 26, 26, 32), (1, 52, 48, 64), (3, 8, 6, 8), (2, 14, 14, 512), (1, 4, 4, 1024)])
+def test_bn_leaky_pool_fused_equals_unfused(ops, shape, mode):
+    """yolo2_bn_leaky_pool / _bwd_reduce / _bwd_apply against the unfused chain bn_leaky -> maxpool_fwd and
+    maxpool_bwd -> bn_leaky_bwd_reduce/apply (themselves checked against the oracle above), ties included."""
+    B, H, W, C = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(C + H)
+    y = (rng.randn(B, H, W, C) * 1.5 + rng.randn(C)).astype(np.float32)
+    y[:, ::2, ::2, : C // 2] = y[:, 1::2, ::2, : C // 2]        # exact ties inside many windows: first-max routing must agree
+    if mode == 'bf16':
+        y = bf16_round(y)
+    gamma = (rng.rand(C) + 0.5).astype(np.float32) * np.where(rng.rand(C) < 0.2, -1, 1).astype(np.float32)   # some negative scales
+    beta = (rng.randn(C) * 0.2).astype(np.float32)
+    M, MP = B * H * W, B * (H // 2) * (W // 2)
+    yd = dev(y, tdtype)
+    mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ws = torch.zeros(1026 * C + 64, dtype=torch.float64, device='cuda')
+    ops.bn_stats(yd, mean, var, ws, M, C)
+    g, b_ = dev(gamma), dev(beta)
+    a = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    p_ref = torch.zeros(MP * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky(yd, mean, var, g, b_, a, M, C, C, 1e-5, 0.1)
+    ops.maxpool_fwd(a, p_ref, B, H, W, C, 2)
+    p = torch.zeros(MP * C, dtype=tdtype, device='cuda')
+    idx = torch.full((MP * C,), 9, dtype=torch.uint8, device='cuda')
+    ops.bn_leaky_pool(yd, mean, var, g, b_, p, idx, B, H, W, C, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(p, p_ref)
+    assert int(idx.max()) <= 3
+    dp = rng.randn(B, H // 2, W // 2, C).astype(np.float32)
+    if mode == 'bf16':
+        dp = bf16_round(dp)
+    dpd = dev(dp, tdtype)
+    da = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.maxpool_bwd(a, dpd, da, B, H, W, C, 2)
+    dg_ref, db_ref = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_leaky_bwd_reduce(da, C, yd, mean, var, g, b_, dg_ref, db_ref, ws, M, C, 1e-5, 0.1)
+    dy_ref = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky_bwd_apply(da, C, yd, mean, var, g, b_, dg_ref, db_ref, dy_ref, M, C, 1e-5, 0.1)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_leaky_pool_bwd_reduce(dpd, C, idx, yd, mean, var, g, b_, dg, db, ws, B, H, W, C, 1e-5, 0.1)
+    dy = torch.full((M * C,), 7.0, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply(dpd, C, idx, yd, mean, var, g, b_, dg_ref, db_ref, dy, B, H, W, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert_close(host(dg), host(dg_ref), 2e-5, 'fused dgamma %s %s' % (shape, mode))
+    assert_close(host(db), host(db_ref), 2e-5, 'fused dbeta %s %s' % (shape, mode))
+    assert_close(host(dy), host(dy_ref), 1e-6 if mode == 'f32' else 8e-3, 'fused dy %s %s' % (shape, mode))
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 26, 26, 32), (4, 13, 13, 1024), (1, 52, 52, 64), (3, 7, 5, 8)])
 def test_bn_leaky_forward_backward(ops, shape, mode):
     B, H, W, C = shape

@@ -153,6 +153,23 @@ class Engine(object):
             self.conv[op['name']] = st
             max_y = max(max_y, B * op['out'].h * op['out'].w * ldy)
             max_c = max(max_c, ldy)
+        # BN + leaky + max-pool fusion: a batch-normalised conv whose output feeds one stride-2 pool and nothing else never
+        # materialises its full-resolution activation (forward) or that activation's gradient (backward)
+        self.fused_pool = {}
+        if os.environ.get('YOLO2_FUSE_POOL', '1') != '0':
+            uses = {}
+            for op in self.graph.ops:
+                for t in (op.get('inputs') or [op['x']]):
+                    uses[t] = uses.get(t, 0) + 1
+            producers = {op['out']: op for op in self.graph.ops if op['kind'] == 'conv'}
+            for op in self.graph.ops:
+                x = op.get('x')
+                if (op['kind'] == 'pool' and op['stride'] == 2 and x in producers and producers[x]['bn'] and uses.get(x, 0) == 1
+                        and x.h % 2 == 0 and x.w % 2 == 0 and self.act[x][1] == x.c and self.act[op['out']][1] == op['out'].c
+                        and self.act[producers[x]['y']][1] == x.c and x.c // (8 if T == torch.bfloat16 else 4) <= 256):
+                    self.fused_pool[x] = op
+                    if self.training:
+                        self.conv[producers[x]['name']]['pool_idx'] = torch.zeros(B * (x.h // 2) * (x.w // 2) * x.c, dtype=torch.uint8, device=dev)
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
@@ -243,13 +260,20 @@ class Engine(object):
                         mean, var = st['mean'], st['var']
                     else:
                         mean, var = mmean, mvar
-                    ob, ldo = self.act[out]
-                    ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
+                    pool = self.fused_pool.get(out)
+                    if pool is not None:
+                        pb, ldp = self.act[pool['out']]
+                        ops.bn_leaky_pool(yb, mean, var, gamma, beta, pb, st.get('pool_idx'), B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA)
+                    else:
+                        ob, ldo = self.act[out]
+                        ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
                 else:
                     ob, ldo = self.act[out]
                     self._conv(xb, st['Ffwd'], self.var[op['biases'].name], ob, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], op['ksize'] ** 2 * op['cin'])
             elif kind == 'pool':
                 x, out = op['x'], op['out']
+                if x in self.fused_pool:
+                    continue                 # produced by the conv's fused BN + leaky + pool pass
                 assert self.act[x][1] == x.c and self.act[out][1] == out.c
                 ops.maxpool_fwd(self.act[x][0], self.act[out][0], B, x.h, x.w, x.c, op['stride'])
             elif kind == 'reorg':
@@ -301,14 +325,23 @@ class Engine(object):
                 if op['bn']:
                     yb, _ = self.act[op['y']]
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
-                    ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
-                                            self.gvar[op['beta'].name], self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
+                    dgam, dbet = self.gvar[op['gamma'].name], self.gvar[op['beta'].name]
+                    pool = self.fused_pool.get(out)
+                    if pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
+                        dpb, lddp = self.gact[pool['out']]
+                        ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,
+                                                     B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
+                    else:
+                        ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
                     slot = (slot + 1) % 3
                     dy = self.dy_ring[slot]
                     if self.dy_free[slot] is not None:
                         main.wait_event(self.dy_free[slot])       # the filter gradient that last read this buffer is done
-                    ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.gvar[op['gamma'].name],
-                                           self.gvar[op['beta'].name], dy, M, cout, BN_EPS, LEAKY_ALPHA)
+                    if pool is not None:
+                        ops.bn_leaky_pool_bwd_apply(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy,
+                                                    B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
+                    else:
+                        ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy, M, cout, BN_EPS, LEAKY_ALPHA)
                     ring = True
                 else:
                     dy = gob
@@ -337,6 +370,8 @@ class Engine(object):
                     on_layer_done(op, done)
             elif kind == 'pool':
                 x, out = op['x'], op['out']
+                if x in self.fused_pool:
+                    continue                 # routed inside the producer's fused BN backward
                 dst, ldd, fin = self._grad_sink(x, written)
                 assert ldd == x.c
                 ops.maxpool_bwd(self.act[x][0], self.gact[out][0], dst, B, x.h, x.w, x.c, op['stride'])

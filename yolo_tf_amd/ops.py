@@ -72,6 +72,21 @@ def bn_leaky_bwd_apply(dA, ldda, Y, mean, var, gamma, beta, dgamma, dbeta, dY, M
          M, C, eps, alpha, dtype_code(Y.dtype), _stream())
 
 
+def bn_leaky_pool(Y, mean, var, gamma, beta, P, idx, B, H, W, C, ldp, eps, alpha):
+    call('yolo2_bn_leaky_pool', ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(P), ptr(idx), B, H, W, C, ldp, eps, alpha,
+         dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_pool_bwd_reduce(dP, lddp, idx, Y, mean, var, gamma, beta, dgamma, dbeta, ws, B, H, W, C, eps, alpha):
+    call('yolo2_bn_leaky_pool_bwd_reduce', ptr(dP), lddp, ptr(idx), ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
+         ptr(ws), B, H, W, C, eps, alpha, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_pool_bwd_apply(dP, lddp, idx, Y, mean, var, gamma, beta, dgamma, dbeta, dY, B, H, W, C, eps, alpha):
+    call('yolo2_bn_leaky_pool_bwd_apply', ptr(dP), lddp, ptr(idx), ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
+         ptr(dY), B, H, W, C, eps, alpha, dtype_code(Y.dtype), _stream())
+
+
 def maxpool_fwd(A, P, B, H, W, C, stride):
     call('yolo2_maxpool_fwd', ptr(A), ptr(P), B, H, W, C, stride, dtype_code(A.dtype), _stream())
 
