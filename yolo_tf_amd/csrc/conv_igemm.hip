@@ -494,8 +494,14 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
+            static const int ns2 = getenv("YOLO2_IGEMM_WIDE_NS2") ? atoi(getenv("YOLO2_IGEMM_WIDE_NS2")) : 1;
             if (wide) Y2_IGEMM_KS_WIDE(0, grid);
-            else Y2_IGEMM_KS_CT(128, 2, 3, 0, 8, grid);
+            else if (ns2 && Cp % (8 * VEC) == 0) {
+                // full grids with >= 64 channels: 128-byte rows on a 2-stage ring (64 KiB: two workgroups per CU, 8 MFMAs per
+                // wave between barriers instead of 4) -- +8..19 % on the 52x52 / 26x26 stages (profiles/r01_igemm_wide_ns2.txt)
+                if (ksize == 3) Y2_IGEMM(128, 2, 2, 3, 0, false, 8, 8, grid);
+                else Y2_IGEMM(128, 2, 2, 1, 0, false, 8, 8, grid);
+            } else Y2_IGEMM_KS_CT(128, 2, 3, 0, 8, grid);
         }
     } else {
         const int NT = 1;
