@@ -507,7 +507,13 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         const int NT = 1;
         ws = nullptr;
         dim3 grid(MT);
-        if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, 0, 4, grid);
+        static const int small_wide = getenv("YOLO2_IGEMM_SMALL_WIDE") ? atoi(getenv("YOLO2_IGEMM_SMALL_WIDE")) : 1;
+        if (small_wide && ksize == 3 && Cp % (8 * VEC) == 0) {
+            // 3x3 with <= 64 filters and >= 64 channels (the 208x208 / 104x104 data gradients): 128-byte rows, 2-stage ring;
+            // +35 % / +20 % on those two launches; the 1x1 layers measured no gain (profiles/r01_igemm_wide_ns2.txt)
+            if (Nf > 32) Y2_IGEMM(64, 1, 2, 3, 0, false, 8, 4, grid);
+            else Y2_IGEMM(32, 1, 2, 3, 0, false, 8, 4, grid);
+        } else if (Nf > 32) Y2_IGEMM_KS_CT(64, 1, 3, 0, 4, grid);
         else Y2_IGEMM_KS_CT(32, 1, 3, 0, 4, grid);
     }
     return 0;
