@@ -326,7 +326,10 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
-    const bool small = Cin <= 64 || Cout <= 64;
+    // few 128x128 tiles (1x1 layers, 128->256 3x3): the 64x64 tile quarters the pixel-range split and its atomic traffic
+    // (26 -> 20 us on the 1x1 layers; profiles/r01_wgrad_small_tiles.txt)
+    static const int small_below = getenv("YOLO2_WGRAD_SMALL_BELOW") ? atoi(getenv("YOLO2_WGRAD_SMALL_BELOW")) : 33;
+    const bool small = Cin <= 64 || Cout <= 64 || ksize * ksize * cdiv(Cin, 128) * cdiv(Cout, 128) < small_below;
     if (small) {
         Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 64, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
     } else {
