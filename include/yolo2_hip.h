@@ -64,7 +64,11 @@ int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, fl
 
 /* Filter gradient of the same convolution (tf.gradients of conv2d, train.py:127-129):
  *   dW[r,s,c,n] += sum_{b,h,w} X[b,h+r-pad,w+s-pad,c] * dY[b,h,w,n]       (HWIO, f32)
- * dW must be zeroed by the caller: pixel-range splits accumulate with f32 atomics. */
+ * dW must be zeroed by the caller when yolo2_conv2d_wgrad_accumulates() says so: pixel-range splits accumulate with
+ * f32 atomics. */
+/* 1 if yolo2_conv2d_wgrad ADDS into dW for this shape (several pixel ranges per tile: the caller must zero dW first),
+ * 0 if it overwrites every element (single range: dW may hold anything).  Pure host query, no launch. */
+int yolo2_conv2d_wgrad_accumulates(int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int ksize, int dtype);
 int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW,
                        int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int ksize,
                        int dtype, void *stream);

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_table_matches_header():
     from yolo_tf_amd import _lib
-    declared = set(_declared()) - {'yolo2_abi_version', 'yolo2_last_error'}
+    declared = set(_declared()) - {'yolo2_abi_version', 'yolo2_last_error', 'yolo2_conv2d_wgrad_accumulates'}   # queries, bound separately
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     _lib.load()
 

@@ -192,6 +192,23 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
 WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]
 
 
+def test_conv_wgrad_single_range_overwrites(ops):
+    """Shapes whose filter gradient is one pixel range per tile store instead of accumulating: dW may be dirty
+    (yolo2_conv2d_wgrad_accumulates == 0); split shapes report 1."""
+    B, H, W, Cin, Cout, k = 2, 13, 13, 1024, 1024, 3          # 576 tiles -> single range
+    assert not ops.conv2d_wgrad_accumulates(B, H, W, Cin, Cin, Cout, Cout, k, torch.bfloat16)
+    assert ops.conv2d_wgrad_accumulates(16, 104, 104, 64, 64, 128, 128, 3, torch.bfloat16)
+    assert ops.conv2d_wgrad_accumulates(16, 416, 416, 3, 8, 32, 32, 3, torch.bfloat16)
+    rng = np.random.RandomState(5)
+    x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
+    dy = bf16_round(rng.randn(B, H, W, Cout).astype(np.float32))
+    ref = R.conv2d_wgrad(x, dy, k, k)
+    dW = torch.full((k * k * Cin * Cout,), 123.0, dtype=torch.float32, device='cuda')     # dirty on purpose
+    ops.conv2d_wgrad(dev(x, torch.bfloat16), dev(dy, torch.bfloat16), dW, B, H, W, Cin, Cin, Cout, Cout, k)
+    torch.cuda.synchronize()
+    assert_close(host(dW).reshape(k, k, Cin, Cout), ref, BF16_RTOL, 'wgrad single range, dirty dW')
+
+
 @pytest.mark.parametrize('shape', WGRAD_SHAPES)
 @pytest.mark.parametrize('mode', ['f32', 'bf16', 'bf16_gather'])
 def test_conv_wgrad(ops, shape, mode):

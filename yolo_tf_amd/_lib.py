@@ -89,6 +89,8 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.restype = _i
         fn.argtypes = args
+    lib.yolo2_conv2d_wgrad_accumulates.restype = _i        # a query (0 / 1), not a status
+    lib.yolo2_conv2d_wgrad_accumulates.argtypes = [_i] * 9
     lib.yolo2_debug_set_wgrad_variant.restype = None
     lib.yolo2_debug_set_wgrad_variant.argtypes = [_i]
     _lib = lib

@@ -32,7 +32,7 @@
 template <typename T, int BC, int BNN, int VARIANT, int NW = 4, int BKPv = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W,
-    int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap) {
+    int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap, int direct) {
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BKP = BKPv ? BKPv : (sizeof(T) == 2 ? 32 : 16);      // pixels per reduction tile
     constexpr int XROWB = BC * sizeof(T), YROWB = BNN * sizeof(T);   // bytes per pixel row of a tile
@@ -251,7 +251,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int c = cb + (r & 3) + 8 * (r >> 2);
-                if (c < Cin) unsafeAtomicAdd(out + (long)c * Cout + n, acc[i][j][r]);
+                if (c < Cin) {
+                    if (direct) out[(long)c * Cout + n] = acc[i][j][r];      // single pixel range: this block owns the element
+                    else unsafeAtomicAdd(out + (long)c * Cout + n, acc[i][j][r]);
+                }
             }
         }
     }
@@ -260,23 +263,21 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
 static int g_wgrad_variant = 0;
 extern "C" void yolo2_debug_set_wgrad_variant(int v) { g_wgrad_variant = v; }
 
-template <typename T, int BC, int BNN, int BKPv = 0>
-static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx,
-                         int Cout, int ldy, int ksize, hipStream_t st) {
-    const int M = B * H * W;
+struct WgradPlan { int tiles, ks, remap, mchunk, blocks; };
+// Pixel-range split (every block ends with one f32 atomic per output element, so fewer, longer blocks =
+// less atomic traffic; more blocks = more latency hiding).  Measured on the Darknet-19 shapes
+// (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
+// blocks for the 128-wide tile / ~1024 for the 64-wide one; with fewer ranges (13x13 stages) it would
+// leave XCDs idle, so those keep the plain mapping (~512 blocks of 8 waves for the 128-wide tile).
+static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN, int BKP) {
+    WgradPlan p;
     const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
-    const int tiles = ksize * ksize * CT * NT;
-    constexpr int BKP = BKPv ? BKPv : (sizeof(T) == 2 ? 32 : 16);
-    // Pixel-range split (every block ends with one f32 atomic per output element, so fewer, longer blocks =
-    // less atomic traffic; more blocks = more latency hiding).  Measured on the Darknet-19 shapes
-    // (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
-    // blocks for the 128-wide tile / ~1024 for the 64-wide one; with fewer ranges (13x13 stages) it would
-    // leave XCDs idle, so those keep the plain mapping (~512 blocks of 8 waves for the 128-wide tile).
+    p.tiles = ksize * ksize * CT * NT;
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
     static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
     const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
     int target = env_target > 0 ? env_target : (BC >= 128 ? 512 : 1024);
-    int ks = cdiv(target, tiles);
+    int ks = cdiv(target, p.tiles);
     int remap = env_remap >= 0 ? env_remap : (ks >= 8 && max_ks >= 8);
     if (remap) {
         ks = cdiv(ks, 8) * 8;
@@ -285,26 +286,58 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     }
     if (!remap) {
         if (env_target <= 0) target = BC >= 128 ? 512 : 1024;
-        ks = cdiv(target, tiles);
+        ks = cdiv(target, p.tiles);
         if (ks > max_ks) ks = max_ks;
     }
     if (ks < 1) ks = 1;
-    int mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
-    ks = cdiv(M, mchunk);
+    p.mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
+    ks = cdiv(M, p.mchunk);
     if (remap && ks % 8 != 0) remap = (ks >= 8);              // rounding may have changed the count; ragged tail is fine
-    dim3 grid(remap ? tiles * (cdiv(ks, 8) * 8) : tiles * ks);
+    p.ks = ks;
+    p.remap = remap;
+    p.blocks = remap ? p.tiles * (cdiv(ks, 8) * 8) : p.tiles * ks;
+    return p;
+}
+
+template <typename T, int BC, int BNN, int BKPv = 0>
+static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx,
+                         int Cout, int ldy, int ksize, hipStream_t st) {
+    const int M = B * H * W;
+    const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
+    constexpr int BKP = BKPv ? BKPv : (sizeof(T) == 2 ? 32 : 16);
+    const WgradPlan pl = wgrad_plan(M, Cin, Cout, ksize, BC, BNN, BKP);
+    const int mchunk = pl.mchunk, remap = pl.remap;
+    const int direct = pl.ks == 1;                            // one pixel range: plain stores, dW need not be zeroed
+    dim3 grid(pl.blocks);
     const unsigned x_bytes = (unsigned)((size_t)M * ldx * sizeof(T)), y_bytes = (unsigned)((size_t)M * ldy * sizeof(T));
     static const int nw8 = getenv("YOLO2_WGRAD_NW8") ? atoi(getenv("YOLO2_WGRAD_NW8")) : 1;
     if constexpr (BC >= 128) {
         if (g_wgrad_variant == 0 && nw8) {
-            conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
+            conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
             return;
         }
     }
     if (g_wgrad_variant == 0)
-        conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
+        conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
     else
-        conv_wgrad_kernel<T, BC, BNN, 1><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap);
+        conv_wgrad_kernel<T, BC, BNN, 1><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
+}
+
+static bool wgrad_small_tile(int Cin, int Cout, int ksize) {
+    // few 128x128 tiles (1x1 layers, 128->256 3x3): the 64x64 tile quarters the pixel-range split and its atomic traffic
+    // (26 -> 20 us on the 1x1 layers; profiles/r01_wgrad_small_tiles.txt)
+    static const int small_below = getenv("YOLO2_WGRAD_SMALL_BELOW") ? atoi(getenv("YOLO2_WGRAD_SMALL_BELOW")) : 33;
+    return Cin <= 64 || Cout <= 64 || ksize * ksize * cdiv(Cin, 128) * cdiv(Cout, 128) < small_below;
+}
+
+extern "C" int yolo2_conv2d_wgrad_accumulates(int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int ksize, int dtype) {
+    if (!(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0) || !(ksize == 1 || ksize == 3) || !(dtype == YOLO2_F32 || dtype == YOLO2_BF16)) return 1;
+    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize)) return 1;      // cross-workgroup atomics
+    if (g_wgrad_variant != 0) return 1;
+    const int bkp = dtype == YOLO2_BF16 ? 32 : 16;
+    const bool small = wgrad_small_tile(Cin, Cout, ksize);
+    return wgrad_plan(B * H * W, Cin, Cout, ksize, small ? 64 : 128, small ? 64 : 128, bkp).ks == 1 ? 0 : 1;
 }
 
 extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin,
@@ -326,10 +359,7 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
-    // few 128x128 tiles (1x1 layers, 128->256 3x3): the 64x64 tile quarters the pixel-range split and its atomic traffic
-    // (26 -> 20 us on the 1x1 layers; profiles/r01_wgrad_small_tiles.txt)
-    static const int small_below = getenv("YOLO2_WGRAD_SMALL_BELOW") ? atoi(getenv("YOLO2_WGRAD_SMALL_BELOW")) : 33;
-    const bool small = Cin <= 64 || Cout <= 64 || ksize * ksize * cdiv(Cin, 128) * cdiv(Cout, 128) < small_below;
+    const bool small = wgrad_small_tile(Cin, Cout, ksize);
     if (small) {
         Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 64, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
     } else {

@@ -63,6 +63,7 @@ class Engine(object):
         self._alloc_activations()
         self.init_variables(seed)
         self._filters_dirty = True
+        self._zero_ranges = None
         self._phase = 'fwd'          # 'fwd' | 'dgrad': which sweep a conv launch belongs to (timer tag)
         self.kernel_timer = None     # optional bench.KernelTimer: HIP events around the dominant conv kernel
 
@@ -232,6 +233,44 @@ class Engine(object):
         assert images.dtype == torch.float32 and images.is_cuda and images.numel() == self.B * inp.h * inp.w * 3
         self.img = images.contiguous()
         ops.image_prep(self.img, self.act[inp][0], self.ws, self.B, inp.h * inp.w, mode)
+
+    def _plan_grad_zeroing(self):
+        """Arena ranges that must be zero before backward: filter gradients that accumulate with atomics (several
+        pixel ranges per tile).  Layers whose filter gradient is a single range store directly -- at batch 16 those are
+        the three 13x13 layers that hold 70 % of the parameters -- and BN / bias gradients are stored by their
+        finalisation kernels, so most of the 268 MB arena is never cleared."""
+        if os.environ.get('YOLO2_ZERO_ALL_GRADS', '0') != '0':
+            return [(0, self.n_params)]
+        ranges = []
+        for op in self.graph.ops:
+            if op['kind'] != 'conv':
+                continue
+            x, out = op['x'], op['out']
+            ldx, ldy = self.act[x][1], pad8(op['cout'])
+            if ops.conv2d_wgrad_accumulates(self.B, x.h, x.w, op['cin'], ldx, op['cout'], ldy, op['ksize'], self.dtype):
+                off, size = self.param_offsets[op['weights'].name]
+                ranges.append((off, off + (size + 3) // 4 * 4))
+        ranges.sort()
+        merged = []
+        for a, b in ranges:
+            if merged and a <= merged[-1][1]:
+                merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+            else:
+                merged.append((a, b))
+        # bridging small gaps costs less than another launch
+        out = []
+        for a, b in merged:
+            if out and a - out[-1][1] <= (1 << 20):
+                out[-1] = (out[-1][0], b)
+            else:
+                out.append((a, b))
+        return out
+
+    def zero_grads(self):
+        if self._zero_ranges is None:
+            self._zero_ranges = self._plan_grad_zeroing()
+        for a, b in self._zero_ranges:
+            self.grads[a:b].zero_()
 
     # ---------------------------------------------------------------- forward
     def forward(self):

@@ -34,6 +34,11 @@ def bn_finalize(bn_part, shift, M, C, mean, var, mm, mv, decay):
     call('yolo2_bn_finalize', ptr(bn_part), ptr(shift), M, C, ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, _stream())
 
 
+def conv2d_wgrad_accumulates(B, H, W, Cin, ldx, Cout, ldy, ksize, dtype):
+    """True when yolo2_conv2d_wgrad adds into dW with atomics for this shape (dW must be zeroed first); False when it overwrites."""
+    return bool(_lib.load().yolo2_conv2d_wgrad_accumulates(B, H, W, Cin, ldx, Cout, ldy, ksize, dtype_code(dtype)))
+
+
 def conv2d_wgrad(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize):
     call('yolo2_conv2d_wgrad', ptr(X), ptr(dY), ptr(dW), B, H, W, Cin, ldx, Cout, ldy, ksize, dtype_code(X.dtype), _stream())
 

@@ -53,7 +53,7 @@ class TrainSession(object):
 
     def forward_backward(self, images):
         e, m = self.engine, self.model
-        e.grads.zero_()
+        e.zero_grads()
         e.set_images(images, self.preprocess_mode)
         e.forward()
         out = e.output()
