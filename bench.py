@@ -32,7 +32,12 @@ import torch         # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MATRIX_PEAK_TFLOPS = 157.3
-IGEMM_HBM_BYTES_PER_LAUNCH = None    # rocprofv3 PMC (FETCH_SIZE/WRITE_SIZE, gfx950-corrected) per forward launch; see profiles/
+# Fabric bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over this
+# same command (scripts/gpu_traffic.sh), FETCH doubled per the guide's gfx950 note, WRITE calibrated 1.00 on bn_leaky_kernel;
+# average over the 37 launches of one step (profiles/r01_hbm_traffic_pmc_final.md: 68.5 MB fetched + 21.8 MB written).  The
+# counters sit between L2 and the fabric: Infinity-Cache hits are included.  Algorithmic bytes (operands once): 27.5 MB.
+IGEMM_HBM_BYTES_PER_LAUNCH = 90.3e6
+IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 27.5e6
 TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
 
 
@@ -213,6 +218,7 @@ def main():
                                'traffic': IGEMM_HBM_BYTES_PER_LAUNCH if (args.dtype == 'bf16' and args.batch == 16 and args.size == 416) else None,
                                'kernel': 'conv_igemm_kernel<%s,...> (implicit-GEMM forward + data-gradient convolutions with > 64 filters)' % args.dtype,
                                'launches': ks['launches'], 'avg_launch_ms': ks['avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
+                               'algorithmic_bytes_per_launch': IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH, 'traffic_unit': 'bytes per launch (PMC, separate passes)',
                                'measured_over': '%d instrumented single-stream training steps run right after the timed region '
                                                 '(events inside it cost 11 %% of the step)' % min(args.steps, 10),
                                'forward_launches_tflops': kf['tflops'] if kf else None, 'data_gradient_launches_tflops': kd['tflops'] if kd else None}

@@ -9,6 +9,6 @@ while IFS= read -r cfg; do
     echo "$cfg rep$rep: $v" | tee -a gpurun_out/ab.log
   done
 done <<CFG
-YOLO2_ZERO_ALL_GRADS=0
-YOLO2_ZERO_ALL_GRADS=1
+YOLO2_COLSUM_BLOCKS=0
+YOLO2_COLSUM_BLOCKS=256
 CFG
