@@ -1,0 +1,36 @@
+"""Per-dispatch SQ counters of scripts/one_layer.py (several rocprofv3 --pmc passes) -> one row per kernel launch of the last repeat."""
+import csv, glob, os, sys
+csv.field_size_limit(1 << 30)
+root = sys.argv[1]
+data = {}     # dispatch order index -> {name, grid, counters}
+for d in sorted(glob.glob(os.path.join(root, 'p*'))):
+    if not os.path.isdir(d):
+        continue
+    rows = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = int(r['Dispatch_Id'])
+            e = rows.setdefault(k, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(int(r['Workgroup_Size']), 1)})
+            e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
+    conv = [rows[k] for k in sorted(rows) if 'conv_igemm' in rows[k]['name'] or 'conv_wgrad' in rows[k]['name']]
+    for i, e in enumerate(conv):
+        data.setdefault(i, {}).update(e)
+keys = ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_LDS_BANK_CONFLICT',
+        'SQ_INSTS_VALU', 'SQ_INSTS_MFMA', 'SQ_INSTS_LDS', 'SQ_INSTS_SALU', 'SQ_INSTS_VMEM_RD', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAIT_INST_LDS', 'SQ_ACTIVE_INST_LDS',
+        'GRBM_GUI_ACTIVE', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_SCA', 'SQ_ACTIVE_INST_MISC', 'SQ_ACTIVE_INST_VMEM']
+print('# SQ counters per launch (scripts/one_layer.py: fwd igemm + wgrad of 6 layers, 3 repeats; last repeat shown)\n')
+print('| kernel | blocks | wave-cycles M | wait_any % | wait_inst % | active_inst % | mfma_busy/busy % | LDS idx active/busy % | bank conf/LDS active % | VALU/MFMA | SALU/MFMA | LDS/MFMA | VMEM/MFMA | wait_inst_lds % |')
+print('|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|')
+n = len(data)
+for i in [j for j in range(n) if j % 6 >= 4]:        # per layer: 3 x (igemm, wgrad); the last repeat
+    e = data[i]
+    g = lambda k: e.get(k, 0.0)
+    wc = g('SQ_WAVE_CYCLES') or 1.0
+    mf = g('SQ_INSTS_MFMA') or 1.0
+    nm = e['name'].replace('void ', '')
+    nm = ('igemm ' if 'igemm' in nm else 'wgrad ') + nm[nm.find('IDF16b') + 6: nm.find('EEv')][:40]
+    print('| %s | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.2f | %.2f | %.2f | %.2f | %.1f |' % (
+        nm, e['grid'], wc / 1e6, 100 * g('SQ_WAIT_ANY') / wc, 100 * g('SQ_WAIT_INST_ANY') / wc, 100 * g('SQ_ACTIVE_INST_ANY') / wc,
+        100 * g('SQ_VALU_MFMA_BUSY_CYCLES') / (g('SQ_BUSY_CYCLES') or 1), 100 * g('SQ_LDS_IDX_ACTIVE') / (g('SQ_BUSY_CYCLES') or 1),
+        100 * g('SQ_LDS_BANK_CONFLICT') / (g('SQ_LDS_IDX_ACTIVE') or 1), g('SQ_INSTS_VALU') / mf, g('SQ_INSTS_SALU') / mf, g('SQ_INSTS_LDS') / mf,
+        g('SQ_INSTS_VMEM_RD') / mf, 100 * g('SQ_WAIT_INST_LDS') / wc))

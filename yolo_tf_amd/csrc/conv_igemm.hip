@@ -31,6 +31,7 @@
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -103,6 +104,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
     const int lrow = lane / CH, lslot = lane % CH;
+    const double rcp_hw = 1.0 / (double)(H * W);
+    const float rcp_w = 1.0f / (float)W;
 
   for (bool first_seg = true;; first_seg = false) {
     int nt, mt, kt_beg = 0, kt_end = nk;
@@ -141,8 +144,15 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         const int m = m0 + r;
         unsigned mask = 0;
         if (m < M) {
-            const int rem = m % (H * W);
-            const int h = rem / W, w = rem - h * W;
+            // (b, h, w) of pixel m without integer division (no hardware divider: ~25 instructions each): reciprocal estimate
+            // + one correction step.  m < 2^31 needs the f64 estimate (error << 1); rem < H*W < 2^24 is exact in f32.
+            const int HW = H * W;
+            int bq = (int)((double)m * rcp_hw);
+            int rem = m - bq * HW;
+            if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
+            int h = (int)((float)rem * rcp_w);
+            int w = rem - h * W;
+            if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
 #pragma unroll
             for (int t = 0; t < KS * KS; ++t) {
                 const int hh = h + t / KS - PAD, ww = w + t % KS - PAD;
@@ -310,41 +320,46 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     // sum(y - shift), sum((y - shift)^2) of the STORED (rounded) outputs to one of Y2_BN_PART_ROWS partial rows: the
     // statistics pass over y (a full re-read of every activation, 21 launches per step) is gone.
     const bool stats = SPLITK != 1 && bn_part != nullptr;
+    auto write_tile = [&](auto checked_tag) {      // interior tiles skip the per-element row test (one VALU compare + branch each)
+        constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= Nf) continue;
-        const float bv = (SPLITK != 1 && bias) ? bias[n] : 0.f;
-        const float sh = stats ? bn_shift[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            if (n >= Nf) continue;
+            const float bv = (SPLITK != 1 && bias) ? bias[n] : 0.f;
+            const float sh = stats ? bn_shift[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+            for (int i = 0; i < TM; ++i) {
+                const int mb = m0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m < M) {
-                    if (SPLITK == 1) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
-                    else {
-                        const T o = (T)(acc[i][j][r] + bv);
-                        O[(long)m * ldo + n] = o;
-                        const float d = (float)o - sh;
-                        s1 += d;
-                        s2 += d * d;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    if (!CHECKED || m < M) {
+                        if (SPLITK == 1) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
+                        else {
+                            const T o = (T)(acc[i][j][r] + bv);
+                            O[(long)m * ldo + n] = o;
+                            const float d = (float)o - sh;
+                            s1 += d;
+                            s2 += d * d;
+                        }
                     }
                 }
             }
-        }
-        if (stats) {      // lanes l and l^32 hold the same column (both pass the n < Nf test together)
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lane < 32) {
-                const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
-                unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
-                unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
+            if (stats) {      // lanes l and l^32 hold the same column (both pass the n < Nf test together)
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32) {
+                    const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                    unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
+                    unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
+                }
             }
         }
-    }
+    };
+    if (m0 + BM <= M) write_tile(std::false_type{});
+    else write_tile(std::true_type{});
     if (SPLITK != 2) break;
   }
 }
