@@ -153,10 +153,11 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             int h = (int)((float)rem * rcp_w);
             int w = rem - h * W;
             if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
-#pragma unroll
-            for (int t = 0; t < KS * KS; ++t) {
-                const int hh = h + t / KS - PAD, ww = w + t % KS - PAD;
-                if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) mask |= 1u << t;
+            if (KS == 3) {      // tap (r, s) is inside the image iff row h+r-1 and column w+s-1 are: outer product of two 3-bit sets
+                const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+                mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
+            } else {
+                mask = 1u;
             }
         }
         a_mask[i] = mask;

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dY), 0, y_lim, 0x00020000);
 
     // per-lane DMA descriptors
+    const double rcp_hw = 1.0 / (double)(H * W);
+    const float rcp_w = 1.0f / (float)W;
     unsigned x_voff[X_IT], y_voff[Y_IT];
     int xh[X_IT], xw[X_IT];
 #pragma unroll
@@ -95,9 +97,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         const int chunk = (lane % XCH) ^ (((r / XRPL) % XSWM) * 4);          // source-side swizzle
         const int c = c0 + chunk * VEC;
         const int m = mbeg + r;
-        const int rem = m % (H * W);
-        xh[i] = rem / W + dh;                                                // shifted coordinates of this row's pixel
-        xw[i] = rem % W + dw;
+        // (h, w) of pixel m without integer division (see conv_igemm.hip): reciprocal estimate + one correction step
+        const int HW = H * W;
+        int rem = m - (int)((double)m * rcp_hw) * HW;
+        if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
+        int hh = (int)((float)rem * rcp_w);
+        int ww = rem - hh * W;
+        if (ww < 0) { ww += W; --hh; } else if (ww >= W) { ww -= W; ++hh; }
+        xh[i] = hh + dh;                                                     // shifted coordinates of this row's pixel
+        xw[i] = ww + dw;
         // channel chunk beyond Cin (or beyond the padded pixel stride): permanently out of range
         x_voff[i] = (c < Cin && c < ldx) ? (unsigned)((long)(m + dh * W + dw) * ldx + c) * (unsigned)sizeof(T) : Y2_OOB;
     }
