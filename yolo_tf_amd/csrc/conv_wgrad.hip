@@ -26,6 +26,7 @@
 // zero-initialised f32 dW with hardware f32 atomics (lanes run along n -> coalesced).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define Y2_OOB 0x80000000u
 
@@ -249,23 +250,29 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
 
     // epilogue: rows = input channels c, cols = filters n; dW is HWIO [tap][Cin][Cout]
     float *out = dW + (long)tap * Cin * Cout;
+    auto write_tile = [&](auto checked_tag) {      // interior tiles skip the per-element channel tests (a branch each)
+        constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-        if (n >= Cout) continue;
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            if (CHECKED && n >= Cout) continue;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int cb = c0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+            for (int i = 0; i < TM; ++i) {
+                const int cb = c0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+                float *col = out + (long)cb * Cout + n;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = cb + (r & 3) + 8 * (r >> 2);
-                if (c < Cin) {
-                    if (direct) out[(long)c * Cout + n] = acc[i][j][r];      // single pixel range: this block owns the element
-                    else unsafeAtomicAdd(out + (long)c * Cout + n, acc[i][j][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int dc = (r & 3) + 8 * (r >> 2);
+                    if (!CHECKED || cb + dc < Cin) {
+                        if (direct) col[(long)dc * Cout] = acc[i][j][r];      // single pixel range: this block owns the element
+                        else unsafeAtomicAdd(col + (long)dc * Cout, acc[i][j][r]);
+                    }
                 }
             }
         }
-    }
+    };
+    if (c0 + BC <= Cin && n0 + BNN <= Cout) write_tile(std::false_type{});
+    else write_tile(std::true_type{});
 }
 
 static int g_wgrad_variant = 0;
