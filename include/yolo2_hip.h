@@ -236,6 +236,42 @@ int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, doub
  * fills out[64*4] with the raw result of ds_read_b64_tr_b16 over a 0..N ramp (layout self-test) */
 int yolo2_selftest_tr16(short *out, void *stream);
 
+/* ---- on-device input pipeline: utils/data/__init__.py:50-109,162-175 + utils/preprocess.py:28-71 after JPEG
+ * decode.  `src` holds the decoded uint8 RGB images back to back (any sizes); per image the caller supplies the
+ * outcome of every random draw of the reference (tf.random_uniform / tf.cond):
+ *   crop_*      tf.image.crop_to_bounding_box arguments (whole image when random_crop is not taken)
+ *   flags       which branches were taken; brightness = delta added (tf.image.random_brightness, max_delta 63),
+ *               saturation / contrast = factors in [0.5, 1.5], hue = delta in [-0.032, 0.032],
+ *               noise_scale = U(5, 15) multiplying tf.truncated_normal (generated on the device from noise_seed)
+ * out: f32 [B, H, W, 3] in 0..255 (tf.clip_by_value), ready for yolo2_image_prep.  ws: >= 3*B doubles when any image
+ * takes the contrast branch (per-channel means of AdjustContrastv2). */
+#define YOLO2_AUG_FLIP 1u
+#define YOLO2_AUG_BRIGHTNESS 2u
+#define YOLO2_AUG_SATURATION 4u
+#define YOLO2_AUG_HUE 8u
+#define YOLO2_AUG_CONTRAST 16u
+#define YOLO2_AUG_NOISE 32u
+#define YOLO2_AUG_GRAY 64u
+typedef struct yolo2_augment_params {
+    long long src_offset;            /* byte offset of the image's first pixel in src */
+    int src_w, src_h;
+    int crop_x, crop_y, crop_w, crop_h;
+    unsigned flags;
+    float brightness, saturation, hue, contrast, noise_scale;
+    unsigned long long noise_seed;
+} yolo2_augment_params;
+int yolo2_augment_images(const unsigned char *src, const yolo2_augment_params *params_device, double *ws, float *out,
+                         int B, int H, int W, int any_contrast, void *stream);
+
+/* transform_labels (utils/data/__init__.py:112-145) for a batch: objects_coord [total,4] = (xmin,ymin,xmax,ymax) in
+ * [0,1], objects_class [total], image b owns objects first_object[b] .. first_object[b+1]-1 (processed in order: the
+ * last object of a cell wins, class bits accumulate).  Outputs are the loss's label tensors, each [B, cells, ...],
+ * bit-exact with the reference.  error_flag (device int, caller zeroes it): bit 0 = object outside the grid or class
+ * out of range (the reference raises IndexError), bit 1 = negative box extent (the reference asserts). */
+int yolo2_transform_labels(const int *objects_class, const float *objects_coord, const int *first_object, float *mask,
+                           float *prob, float *coords, float *offset_xy_min, float *offset_xy_max, float *areas, int B,
+                           int classes, int cell_width, int cell_height, int *error_flag, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

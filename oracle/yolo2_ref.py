@@ -701,3 +701,152 @@ def detect(spec, params, x, classes, anchors, threshold=0.3, threshold_iou=0.4):
     for b in range(conf.shape[0]):
         orders.append(non_max_suppress_fast(conf[b], m['xy_min'][b], m['xy_max'][b], threshold, threshold_iou))
     return conf, m['xy_min'], m['xy_max'], orders
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Input pipeline: utils/data/__init__.py:50-109,162-175 and utils/preprocess.py:28-71.
+# The image arithmetic lives in TensorFlow 1.0 (tf.image.*), which is not under /root/reference and cannot run
+# here: PARITY UNPINNED for these functions -- they restate the published TF-1.0 kernels ([TF-sem]:
+# ResizeBilinear align_corners=False, RGBToHSV / HSVToRGB, AdjustContrastv2, rgb_to_grayscale weights) in float32
+# in the kernels' operation order.  The box arithmetic (random_crop, flip, resize factor) is the reference's own.
+# ---------------------------------------------------------------------------------------------------------
+def random_crop_box(objects_coord, width_height, u4, scale):
+    """utils/preprocess.py:28-42 given the four uniforms u4 ~ U(0, scale) it draws.  objects_coord [K,4] pixels.
+    Returns (coords shifted into the crop, integer crop (x0, y0, w, h) for crop_to_bounding_box, float _wh)."""
+    f = np.float32
+    coord = np.asarray(objects_coord, f)
+    wh = np.asarray(width_height, f)
+    xy_min = coord[:, :2].min(0)
+    xy_max = coord[:, 2:].max(0)
+    margin = wh - xy_max
+    shrink = np.asarray(u4, f) * np.concatenate([xy_min, margin]).astype(f)
+    _xy_min = shrink[:2]
+    _wh = wh - shrink[2:] - _xy_min
+    coord = coord - np.tile(_xy_min, 2)
+    x0, y0 = int(_xy_min[0]), int(_xy_min[1])          # tf.cast(float -> int32) truncates
+    w, h = int(_wh[0]), int(_wh[1])
+    return coord, (x0, y0, w, h), _wh
+
+
+def resize_bilinear(image, out_h, out_w):
+    """tf.image.resize_images(image, [h, w]) of TF 1.0 = ResizeBilinear, align_corners=False: in = out * (in/out) (no
+    half-pixel offset), top-left / bottom-right taps, f32.  Same size -> returned unchanged (resize_images' shortcut)."""
+    f = np.float32
+    img = np.asarray(image, f)
+    in_h, in_w = img.shape[:2]
+    if (in_h, in_w) == (out_h, out_w):
+        return img
+    hs, ws = f(in_h) / f(out_h), f(in_w) / f(out_w)
+    ys = np.arange(out_h, dtype=f) * hs
+    xs = np.arange(out_w, dtype=f) * ws
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    y1 = np.minimum(np.ceil(ys).astype(np.int64), in_h - 1)
+    x1 = np.minimum(np.ceil(xs).astype(np.int64), in_w - 1)
+    ly = (ys - y0.astype(f))[:, None, None]
+    lx = (xs - x0.astype(f))[None, :, None]
+    tl, tr = img[y0][:, x0], img[y0][:, x1]
+    bl, br = img[y1][:, x0], img[y1][:, x1]
+    top = tl + (tr - tl) * lx
+    bottom = bl + (br - bl) * lx
+    return (top + (bottom - top) * ly).astype(f)
+
+
+def resize_coords(objects_coord, crop_wh, width, height):
+    """utils/data/__init__.py:63-68: factor = [width, height] / width_height (the FLOAT extent random_crop returned)."""
+    f = np.float32
+    factor = np.array([width, height], f) / np.asarray(crop_wh, f)
+    return np.asarray(objects_coord, f) * np.tile(factor, 2)
+
+
+def flip_coords(objects_coord, width):
+    """utils/preprocess.py:45-51."""
+    c = np.asarray(objects_coord, np.float32)
+    w = np.float32(width)
+    return np.stack([w - c[:, 2], c[:, 1], w - c[:, 0], c[:, 3]], 1)
+
+
+def rgb_to_hsv(rgb):
+    """TF RGBToHSV kernel, f32 (scale-free in V)."""
+    f = np.float32
+    r, g, b = [np.asarray(rgb[..., i], f) for i in range(3)]
+    v = np.maximum(np.maximum(r, g), b)
+    rng = v - np.minimum(np.minimum(r, g), b)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        s = np.where(v > 0, rng / v, f(0)).astype(f)
+        norm = (f(1) / (f(6) * rng)).astype(f)
+        h = np.where(r == v, norm * (g - b), np.where(g == v, norm * (b - r) + f(2.0 / 6.0), norm * (r - g) + f(4.0 / 6.0))).astype(f)
+    h = np.where(rng <= 0, f(0), h)
+    h = np.where(h < 0, h + f(1), h).astype(f)
+    return np.stack([h, s, v], -1)
+
+
+def hsv_to_rgb(hsv):
+    """TF HSVToRGB kernel, f32."""
+    f = np.float32
+    h, s, v = [np.asarray(hsv[..., i], f) for i in range(3)]
+    c = s * v
+    m = v - c
+    dh = h * f(6)
+    fmodu = dh.copy()
+    fmodu = np.where(fmodu <= 0, fmodu + f(2) * np.ceil((-fmodu) / f(2) + (fmodu == np.floor(fmodu / 2) * 2)), fmodu)   # while (<= 0) += 2
+    fmodu = (fmodu - f(2) * np.floor(fmodu / f(2))).astype(f)            # while (>= 2) -= 2
+    x = c * (f(1) - np.abs(fmodu - f(1)))
+    cat = dh.astype(np.int32)
+    z = np.zeros_like(c)
+    rr = np.select([cat == 0, cat == 1, cat == 4, cat == 5], [c, x, x, c], z)
+    gg = np.select([cat == 0, cat == 1, cat == 2, cat == 3], [x, c, c, x], z)
+    bb = np.select([cat == 2, cat == 3, cat == 4, cat == 5], [x, c, c, x], z)
+    return np.stack([rr + m, gg + m, bb + m], -1).astype(f)
+
+
+def adjust_saturation(image, factor):
+    hsv = rgb_to_hsv(image)
+    hsv[..., 1] = np.clip(hsv[..., 1] * np.float32(factor), 0, 1)
+    return hsv_to_rgb(hsv)
+
+
+def adjust_hue(image, delta):
+    hsv = rgb_to_hsv(image)
+    hsv[..., 0] = np.mod(hsv[..., 0] + (np.float32(1) + np.float32(delta)), np.float32(1)).astype(np.float32)
+    return hsv_to_rgb(hsv)
+
+
+def adjust_contrast(image, factor):
+    """AdjustContrastv2: per-channel mean over H x W."""
+    img = np.asarray(image, np.float32)
+    mean = img.mean((0, 1), dtype=np.float64).astype(np.float32)
+    return ((img - mean) * np.float32(factor) + mean).astype(np.float32)
+
+
+def rgb_to_grayscale3(image):
+    """tf.image.rgb_to_grayscale weights, tiled back to 3 channels (utils/preprocess.py:63-71)."""
+    img = np.asarray(image, np.float32)
+    g = img[..., 0] * np.float32(0.2989) + img[..., 1] * np.float32(0.5870) + img[..., 2] * np.float32(0.1140)
+    return np.repeat(g[..., None], 3, -1).astype(np.float32)
+
+
+def augment_image(src_u8, p, width, height):
+    """load_image_labels image path (utils/data/__init__.py:162-172) for ONE image with every random draw supplied in
+    the dict p: crop (x0,y0,w,h) or None, flip, brightness / saturation / hue / contrast (None = branch not taken),
+    noise (None or an [H,W,3] array already scaled), gray.  Returns f32 [height, width, 3] in 0..255."""
+    img = np.asarray(src_u8, np.float32)
+    if p.get('crop') is not None:
+        x0, y0, w, h = p['crop']
+        img = img[y0:y0 + h, x0:x0 + w]
+    img = resize_bilinear(img, height, width)
+    if p.get('flip'):
+        img = img[:, ::-1]
+    if p.get('brightness') is not None:
+        img = img + np.float32(p['brightness'])
+    if p.get('saturation') is not None:
+        img = adjust_saturation(img, p['saturation'])
+    if p.get('hue') is not None:
+        img = adjust_hue(img, p['hue'])
+    if p.get('contrast') is not None:
+        img = adjust_contrast(img, p['contrast'])
+    if p.get('noise') is not None:
+        img = img + np.asarray(p['noise'], np.float32)
+    if p.get('gray'):
+        img = rgb_to_grayscale3(img)
+    return np.clip(img, 0, 255).astype(np.float32)

@@ -8,8 +8,11 @@ Same flags (-c -t -e -p -s -d -b -o -n -g -lr --seed --summary_secs --save_secs 
 --task); same logdir/cachedir layout, auto-resume from the latest checkpoint in logdir, `-d` wipes
 it, `-t/-e` transfers variables.  One process per GPU; `-b` is the per-GPU batch.  The reference's
 TFRecord/JPEG input pipeline is out of the hot-path scope: batches come from
-``--data synthetic`` (seeded generator, default) or ``--data file.npz`` (images uint8 [N,H,W,3],
-labels produced by utils.data.transform_labels)."""
+``--data synthetic`` (seeded generator, default) or ``--data file.npz``: either pre-made labels (images uint8
+[N,H,W,3] + the six tensors of utils.data.transform_labels) or decoded images with raw boxes (images,
+objects_class [total], objects_coord [total,4] pixels, objects_first [N+1]); the latter goes through the on-device
+input pipeline (utils/augment.py: crop / resize / colour augmentation per config.ini [data_augmentation_*], labels
+built on the GPU) -- the counterpart of the reference's load_image_labels after JPEG decode."""
 import argparse
 import configparser
 import logging
@@ -80,6 +83,22 @@ class NpzData(object):
         return images, tuple(l[idx] for l in self.labels)
 
 
+class DeviceAugmentedData(object):
+    """Decoded images + raw boxes resident in HBM -> augmented batch and label tensors, all on the device."""
+
+    def __init__(self, z, batch, width, height, classes, cell_width, cell_height, config, seed, rank, world, session):
+        from yolo_tf_amd.utils.augment import DeviceInputPipeline
+        images = list(z['images'])
+        first = z['objects_first']
+        objects = [(z['objects_class'][first[i]:first[i + 1]], z['objects_coord'][first[i]:first[i + 1]]) for i in range(len(images))]
+        self.pipe = DeviceInputPipeline(images, objects, batch, width, height, classes, cell_width, cell_height, config=config,
+                                        seed=seed, rank=rank, world=world)
+        self.session = session
+
+    def next(self):
+        return self.pipe.next(self.session), None          # labels were written into the session's buffers in place
+
+
 def main():
     rank, local_rank, world = init_distributed()
     torch.cuda.set_device(local_rank)
@@ -114,6 +133,9 @@ def main():
     logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
     if args.data == 'synthetic':
         data = SyntheticData(args.batch_size, len(builder.names), width, height, cell_width, cell_height, seed * world + rank + 1)
+    elif 'objects_coord' in np.load(args.data, allow_pickle=True).files:
+        data = DeviceAugmentedData(np.load(args.data, allow_pickle=True), args.batch_size, width, height, len(builder.names), cell_width, cell_height,
+                                   config, seed, rank, world, session)
     else:
         data = NpzData(args.data, args.batch_size, seed, rank, world)
     last_summary = last_save = t_rate = time.time()

@@ -35,6 +35,8 @@ SIGNATURES = {
     'yolo2_bn_leaky_pool': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
+    'yolo2_augment_images': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'yolo2_transform_labels': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],
     'yolo2_bn_stats_ema': [_p, _p, _p, _p, _p, ctypes.c_double, _p, _l, _i, _i, _p],
     'yolo2_bn_ema': [_p, _p, _p, _p, _i, ctypes.c_double, _p],
@@ -61,6 +63,13 @@ SIGNATURES = {
     'yolo2_clip_by_norm': [_p, _p, _i, _f, _p, _p],
     'yolo2_selftest_tr16': [_p, _p],
 }
+
+class AugmentParams(ctypes.Structure):
+    """yolo2_augment_params (include/yolo2_hip.h)."""
+    _fields_ = [('src_offset', ctypes.c_longlong), ('src_w', _i), ('src_h', _i), ('crop_x', _i), ('crop_y', _i), ('crop_w', _i), ('crop_h', _i),
+                ('flags', ctypes.c_uint), ('brightness', _f), ('saturation', _f), ('hue', _f), ('contrast', _f), ('noise_scale', _f),
+                ('noise_seed', ctypes.c_ulonglong)]
+
 
 class FilterDesc(ctypes.Structure):
     """yolo2_filter_desc of include/yolo2_hip.h"""

@@ -15,6 +15,7 @@ SOURCES = {
     'elementwise.hip': [],
     'head.hip': ['-ffp-contract=off'],
     'nms.hip': ['-ffp-contract=off'],
+    'augment.hip': ['-ffp-contract=off'],
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 LIB = os.path.join(HERE, 'libyolo2hip.so')

@@ -186,3 +186,13 @@ def selftest_tr16():
 
 def set_wgrad_variant(v):
     _lib.load().yolo2_debug_set_wgrad_variant(int(v))
+
+
+def augment_images(src, params_dev, ws, out, B, H, W, any_contrast):
+    call('yolo2_augment_images', ptr(src), ptr(params_dev), ptr(ws), ptr(out), B, H, W, int(bool(any_contrast)), _stream())
+
+
+def transform_labels(objects_class, objects_coord, first_object, mask, prob, coords, offset_xy_min, offset_xy_max, areas, B, classes,
+                     cell_width, cell_height, error_flag):
+    call('yolo2_transform_labels', ptr(objects_class), ptr(objects_coord), ptr(first_object), ptr(mask), ptr(prob), ptr(coords),
+         ptr(offset_xy_min), ptr(offset_xy_max), ptr(areas), B, classes, cell_width, cell_height, ptr(error_flag), _stream())
