@@ -44,6 +44,28 @@ for b in batches:
 host_ms = (time.time() - t0) / len(batches) * 1e3
 print('device: %.3f ms per batch of %d (incl. parameter upload) = %.0f img/s; algorithmic bytes %.1f MB (source crop read once x2 passes + f32 out) -> %.2f TB/s; host draw + box transforms %.3f ms per batch'
       % (ms, B, B / ms * 1e3, (2 * src_bytes + out_bytes) / 1e6, (2 * src_bytes + out_bytes) / ms / 1e9, host_ms))
+# kernels alone (parameters already on the device)
+arr, cls, box, first = batches[0]
+params = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+for flagset, name in ((None, 'all branches'), (0, 'resize only'), (A.CONTRAST, 'contrast only'), (A.NOISE, 'noise only'), (A.SATURATION | A.HUE, 'saturation+hue')):
+    arr2 = type(arr)()
+    for d, s_ in zip(arr2, arr):
+        for f_, _t in d._fields_:
+            setattr(d, f_, getattr(s_, f_))
+        if flagset is not None:
+            d.flags = flagset
+    pd = torch.frombuffer(bytearray(bytes(arr2)), dtype=torch.uint8).cuda()
+    anyc = any(x.flags & A.CONTRAST for x in arr2)
+    for _ in range(3):
+        ops.augment_images(pipe.src, pd, pipe.ws, pipe.out, B, H, W, anyc)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(20):
+        ops.augment_images(pipe.src, pd, pipe.ws, pipe.out, B, H, W, anyc)
+    e.record()
+    torch.cuda.synchronize()
+    t = a.elapsed_time(e) / 20
+    print('  augment kernels, %-16s %.1f us per batch  (%.2f TB/s of f32 output alone)' % (name + ':', t * 1e3, out_bytes / t / 1e9))
 # CPU: the oracle on one image with the same branches
 p = dict(crop=(10, 8, 400, 300), flip=True, brightness=20.0, saturation=1.2, hue=0.01, contrast=1.1, noise=None, gray=False)
 t0 = time.time(); n = 0

@@ -118,21 +118,46 @@ __global__ __launch_bounds__(256) void augment_sums_kernel(const unsigned char *
     }
 }
 
-__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {     // splitmix64 finaliser
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
+__device__ __forceinline__ unsigned hash32(unsigned x) {       // "lowbias32" integer finaliser
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
-// standard normal truncated to |z| <= 2 by resampling (tf.truncated_normal), counter-based: (seed, element, attempt)
-__device__ __forceinline__ float truncated_normal(unsigned long long seed, unsigned long long element) {
-    for (unsigned attempt = 0; attempt < 64; ++attempt) {
-        const unsigned long long r = mix64(seed ^ mix64(element * 64 + attempt + 0x9e3779b97f4a7c15ull));
-        const float u1 = ((float)(unsigned)(r >> 40) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
-        const float u2 = (float)(unsigned)((r >> 8) & 0xffffff) * (1.0f / 16777216.0f);   // [0, 1)
-        const float z = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
-        if (fabsf(z) <= 2.0f) return z;
+// Three standard normals truncated to |z| <= 2 by resampling (tf.truncated_normal), counter-based on (seed, pixel):
+// two Box-Muller pairs per pixel from four 24-bit uniforms; a component beyond 2 sigma (4.6 %) is redrawn on its own
+// counter stream.  Fast-math log / sincos: this is noise, not parity arithmetic.
+__device__ __forceinline__ void box_muller(unsigned a, unsigned b, float &z0, float &z1) {
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);               // [0, 1)
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+__device__ __forceinline__ void truncated_normal3(unsigned long long seed, unsigned pixel, float (&z)[3]) {
+    const unsigned s0 = (unsigned)seed, s1 = (unsigned)(seed >> 32);
+    const unsigned base = hash32(pixel ^ s0) + s1;
+    float t[4];
+    box_muller(hash32(base), hash32(base + 0x9e3779b9u), t[0], t[1]);
+    box_muller(hash32(base + 0x3c6ef372u), hash32(base + 0xdaa66d2bu), t[2], t[3]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = t[c];
+        if (fabsf(v) > 2.0f) {
+            v = fabsf(t[3]) <= 2.0f && c == 0 ? t[3] : 3.0f;           // the spare fourth sample serves the first reject
+            unsigned ctr = hash32(base ^ (0x85ebca6bu * (unsigned)(c + 1)));
+            for (int attempt = 0; attempt < 32 && fabsf(v) > 2.0f; ++attempt) {
+                float w;
+                box_muller(hash32(ctr), hash32(ctr + 0x9e3779b9u), v, w);
+                if (fabsf(v) > 2.0f) v = w;
+                ctr += 0x632be5abu;
+            }
+            if (fabsf(v) > 2.0f) v = 0.f;
+        }
+        z[c] = v;
     }
-    return 0.f;
 }
 
 // pass B: the whole chain, f32 [B, H, W, 3] out
@@ -154,10 +179,11 @@ __global__ __launch_bounds__(256) void augment_apply_kernel(const unsigned char 
             v.b = (v.b - mean[2]) * p.contrast + mean[2];
         }
         if (p.flags & YOLO2_AUG_NOISE) {
-            const unsigned long long e = (unsigned long long)i * 3;
-            v.r = v.r + truncated_normal(p.noise_seed, e) * p.noise_scale;
-            v.g = v.g + truncated_normal(p.noise_seed, e + 1) * p.noise_scale;
-            v.b = v.b + truncated_normal(p.noise_seed, e + 2) * p.noise_scale;
+            float z[3];
+            truncated_normal3(p.noise_seed, (unsigned)i, z);
+            v.r = v.r + z[0] * p.noise_scale;
+            v.g = v.g + z[1] * p.noise_scale;
+            v.b = v.b + z[2] * p.noise_scale;
         }
         if (p.flags & YOLO2_AUG_GRAY) {
             const float g = (v.r * 0.2989f + v.g * 0.5870f) + v.b * 0.1140f;
