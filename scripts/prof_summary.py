@@ -41,4 +41,5 @@ def main():
     for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print('| `%s` | %.1f | %.1f | %.1f | %.2f |' % (n, c / steps, t / c, t / steps, 100 * t / tot))
 
-main()
+if __name__ == "__main__":
+    main()
