@@ -52,10 +52,9 @@ template <> struct Mma<float> {
 #define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
-// DBG (timing ablations only, results are wrong): 1 = skip the A-operand DMA, 2 = skip B, 3 = skip both, 4 = skip MFMA
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
 // CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
-template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int DBG = 0, int CH = 4, int NW = 4, int BMv = 128>
+template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int CH = 4, int NW = 4, int BMv = 128>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
@@ -72,8 +71,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     constexpr int A_IT = BM / RPI / NW;    // DMA instructions per wave per tile
     constexpr int B_PIECES = BN / RPI;
     constexpr int B_IT = (B_PIECES + NW - 1) / NW;
-    constexpr bool NOA = (DBG == 1 || DBG == 3 || DBG >= 5), NOB = (DBG == 2 || DBG == 3 || DBG >= 5);
-    constexpr int LOADS = (NOA ? 0 : A_IT) + (NOB ? 0 : B_IT);   // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
+    constexpr int LOADS = A_IT + B_IT;   // counted on vmcnt; identical in every wave (idle B slots still issue, all-OOB)
     constexpr int PAD = KS / 2;
     constexpr int STAGE = (BM + B_IT * NW * RPI) * ROWB;
     static_assert(A_IT >= 1, "at least one A piece per wave");
@@ -198,14 +196,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         unsigned char *As = smem + i_stage * STAGE;
         unsigned char *Bs = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < (NOA ? 0 : A_IT); ++i) {
+        for (int i = 0; i < A_IT; ++i) {
             bool ok = (a_mask[i] & tapbit) != 0;
             if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
             const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < (NOB ? 0 : B_IT); ++i) {
+        for (int i = 0; i < B_IT; ++i) {
             unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
             if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
@@ -233,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (DBG != 5 && DBG != 7) __builtin_amdgcn_s_barrier();      // tile kt complete in LDS for every wave; tile kt-1's buffer is free
+        __builtin_amdgcn_s_barrier();      // tile kt complete in LDS for every wave; tile kt-1's buffer is free
         if (kt_issue < kt_end) issue_next();
         const unsigned char *As = smem + c_stage * STAGE + (wm * TM * 32 + frow) * ROWB;
         const unsigned char *Bs = smem + c_stage * STAGE + (BM + wn * TN * 32 + frow) * ROWB;
@@ -251,19 +249,17 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (DBG >= 6) { af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(smem + (lane & 31) * ROWB); asm volatile("" : "+v"(af[i])); }
-                else af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
+                af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (DBG >= 6) { bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(smem + (lane & 31) * ROWB + 16); asm volatile("" : "+v"(bf[j])); }
-                else bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
+                bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    if (DBG == 4) { asm volatile("" ::"v"(af[i]), "v"(bf[j])); } else acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+                    acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
                 }
         }
     }
@@ -429,7 +425,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 }
 
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
-    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, 0, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
+    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
         (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
