@@ -98,6 +98,13 @@ typedef struct yolo2_filter_desc {
 int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype,
                             void *stream);
 
+/* Inference form of a batch-normalised layer with the moving statistics folded into the operands
+ * (W' = W * gamma/sqrt(var+eps) per output channel, bias' = beta - mean*gamma/sqrt(var+eps)):
+ *   O = leaky_relu(conv(P, F') + bias', alpha)      -- conv + batch_norm(is_training=False) + leaky_relu of
+ * model/yolo2/inference.py:62-66,73-112 in one launch; as yolo2_conv2d_ws otherwise. */
+int yolo2_conv2d_bias_leaky(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B,
+                            int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, float alpha, int dtype, void *stream);
+
 /* Forward convolution of a batch-normalised layer (no bias): as yolo2_conv2d_ws, and the per-channel shifted sums
  *   sum_m (y[m,n] - shift[n]),  sum_m (y[m,n] - shift[n])^2        (y = the stored, rounded output)
  * are accumulated into bn_part, f32 [2][YOLO2_BN_PART_ROWS][Nf], by the convolution's own epilogue (f32 atomics on

@@ -58,7 +58,7 @@ template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAI
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags, float act_alpha) {
     constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
@@ -335,7 +335,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                     if (!CHECKED || m < M) {
                         if (SPLITK == 1) unsafeAtomicAdd(Oacc + (long)m * Nf + n, acc[i][j][r]);
                         else {
-                            const T o = (T)(acc[i][j][r] + bv);
+                            float v = acc[i][j][r] + bv;
+                            if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);      // leaky ReLU of a BN-folded inference layer
+                            const T o = (T)v;
                             O[(long)m * ldo + n] = o;
                             const float d = (float)o - sh;
                             s1 += d;
@@ -363,12 +365,14 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
 
 // f32 partial sums [M][Nf] -> O (dtype, pixel stride ldo) + bias
 template <typename T>
-__global__ void splitk_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, T *__restrict__ O, long M, int Nf, int ldo) {
+__global__ void splitk_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, T *__restrict__ O, long M, int Nf, int ldo, float act_alpha) {
     const long total = M * Nf;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long m = i / Nf;
         const int n = (int)(i - m * Nf);
-        O[m * ldo + n] = (T)(acc[i] + (bias ? bias[n] : 0.f));
+        float v = acc[i] + (bias ? bias[n] : 0.f);
+        if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
+        O[m * ldo + n] = (T)v;
     }
 }
 
@@ -426,7 +430,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
     conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
-        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags)
+        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
 #define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
@@ -447,7 +451,7 @@ static int choose_ksplit(int tiles, int nk, int target) {
 
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
-                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done) {
+                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done, float act_alpha) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
@@ -502,7 +506,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             Y2_IGEMM_KS_CT(128, 2, 3, 1, 4, grid);     // 4-wave workgroups: 3 per CU, measured best with slicing
             long total = (long)M * Nf;
             int g = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-            splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo);
+            splitk_finish_kernel<T><<<g, 256, 0, st>>>(ws, bias, (T *)O, M, Nf, ldo, act_alpha);
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
@@ -533,7 +537,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
 
 static int conv2d_impl(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H,
                        int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn,
-                       const float *bn_shift = nullptr, float *bn_part = nullptr) {
+                       const float *bn_shift = nullptr, float *bn_part = nullptr, float act_alpha = 1.0f) {
     if (!(P && F && O) || !(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0) || !(ksize == 1 || ksize == 3) || !(ldp >= Cp && ldo >= Nf)) {
         yolo2_set_error("%s: argument check failed: pointers / extents / ksize / strides", fn);
         return YOLO2_E_ARG;
@@ -549,7 +553,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     }
     int rc = 0;
     static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
-    if (first_direct && !bias && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
+    if (first_direct && !bias && act_alpha == 1.0f && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
         Y2_CHECK_LAUNCH();
@@ -557,7 +561,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     }
     bool stats_done = true;
     Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
-                                                 bn_shift, bn_part, &stats_done));
+                                                 bn_shift, bn_part, &stats_done, act_alpha));
     if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
     Y2_CHECK_LAUNCH();
     if (bn_part && !stats_done)       // K-sliced path: statistics from a pass over the finished output
@@ -577,6 +581,12 @@ extern "C" int yolo2_conv2d_bn(const void *P, const void *F, void *O, float *ws,
         return YOLO2_E_ARG;
     }
     return conv2d_impl(P, F, nullptr, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_bn", shift, bn_part);
+}
+
+extern "C" int yolo2_conv2d_bias_leaky(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
+                                       int Cp, int ldp, int Nf, int ldo, int ksize, float alpha, int dtype, void *stream) {
+    if (!bias) { yolo2_set_error("yolo2_conv2d_bias_leaky: bias is NULL"); return YOLO2_E_ARG; }
+    return conv2d_impl(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_bias_leaky", nullptr, nullptr, alpha);
 }
 
 extern "C" int yolo2_conv2d_ws(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B,

@@ -173,6 +173,7 @@ class Engine(object):
                         self.conv[producers[x]['name']]['pool_idx'] = torch.zeros(B * (x.h // 2) * (x.w // 2) * x.c, dtype=torch.uint8, device=dev)
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
+        self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
         self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
         self.conv_ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device=dev)   # stream-K: flags + one f32 tile slot per CU
@@ -215,7 +216,11 @@ class Engine(object):
             for d, op in zip(arr, convs):
                 st = self.conv[op['name']]
                 k, ldcin, ldcout = op['ksize'], pad8(op['cin']), pad8(op['cout'])
-                d.W = self.var[op['weights'].name].data_ptr()
+                if self._folds(op):
+                    # inference: moving statistics folded into the filter (W * gamma/sigma) and a bias (beta - mean*gamma/sigma)
+                    st['fold_w'] = torch.empty_like(self.var[op['weights'].name])
+                    st['fold_bias'] = torch.empty(op['cout'], dtype=torch.float32, device=self.device)
+                d.W = (st['fold_w'] if 'fold_w' in st else self.var[op['weights'].name]).data_ptr()
                 d.Ffwd = st['Ffwd'].data_ptr()
                 d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
                 d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
@@ -223,8 +228,20 @@ class Engine(object):
             raw = bytes(arr)
             self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
             self._fdesc_n, self._fdesc_blocks = len(convs), first
+        for op in self.graph.ops:
+            if op['kind'] == 'conv' and 'fold_w' in self.conv[op['name']]:
+                st = self.conv[op['name']]
+                scale = self.var[op['gamma'].name] / torch.sqrt(self.var[op['moving_variance'].name] + BN_EPS)
+                torch.mul(self.var[op['weights'].name].view(op['ksize'], op['ksize'], op['cin'], op['cout']), scale, out=st['fold_w'].view(op['ksize'], op['ksize'], op['cin'], op['cout']))
+                torch.sub(self.var[op['beta'].name], self.var[op['moving_mean'].name] * scale, out=st['fold_bias'])
         ops.filter_prep_batch(self._fdesc, self._fdesc_n, self._fdesc_blocks, self.dtype)
         self._filters_dirty = False
+
+    def _folds(self, op):
+        """Inference-only BN folding applies to batch-normalised layers whose output is a plain activation tensor: not the
+        image layer (its direct kernel has no bias path) and not a layer fused with its max pool."""
+        return (not self.training and self.fold_bn and op['bn'] and op['out'] not in self.fused_pool
+                and op['x'] not in self.graph.inputs.values())
 
     def set_images(self, images, mode=0):
         """images: f32 [B,H,W,3] device tensor (0..255 for mode 0/1).  mode 0 = per_image_standardization
@@ -283,7 +300,10 @@ class Engine(object):
                 xb, ldx = self.act[x]
                 st = self.conv[op['name']]
                 M = B * out.h * out.w
-                if op['bn']:
+                if op['bn'] and 'fold_bias' in st:
+                    ob, ldo = self.act[out]
+                    ops.conv2d_bias_leaky(xb, st['Ffwd'], st['fold_bias'], ob, self.conv_ws, B, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], LEAKY_ALPHA)
+                elif op['bn']:
                     yb, ldy = self.act[op['y']]
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     mmean, mvar = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]

@@ -25,6 +25,11 @@ def conv2d_ws(P, F, bias, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize):
          dtype_code(P.dtype), _stream())
 
 
+def conv2d_bias_leaky(P, F, bias, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, alpha):
+    call('yolo2_conv2d_bias_leaky', ptr(P), ptr(F), ptr(bias), ptr(O), ptr(ws), ws.numel() * ws.element_size(), B, H, W, Cp, ldp, Nf, ldo, ksize,
+         alpha, dtype_code(P.dtype), _stream())
+
+
 def conv2d_bn(P, F, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, shift, bn_part):
     call('yolo2_conv2d_bn', ptr(P), ptr(F), ptr(O), ptr(ws), ws.numel() * ws.element_size(), B, H, W, Cp, ldp, Nf, ldo, ksize,
          ptr(shift), ptr(bn_part), dtype_code(P.dtype), _stream())
