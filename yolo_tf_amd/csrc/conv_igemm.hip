@@ -376,12 +376,11 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
     }
 }
 
-struct Tune { int target_blocks; int wide; int remap; int stream; int cus; int stream_max_tiles; int bm256; int bm256_stream_tiles; };
+struct Tune { int target_blocks; int wide; int remap; int stream; int cus; int stream_max_tiles; int bm256; };
 static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
     static Tune t = [] {
-        Tune v{352, 1, -1, 1, 256, 255, 1, 0};
+        Tune v{352, 1, -1, 1, 256, 255, 1};   // K slicing only for grids below half the chip (see choose_ksplit)
         if (const char *e = getenv("YOLO2_IGEMM_BM256")) v.bm256 = atoi(e);
-        if (const char *e = getenv("YOLO2_IGEMM_BM256_STREAM_TILES")) v.bm256_stream_tiles = atoi(e);   // K slicing only for grids below half the chip (see choose_ksplit)
         if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);
         int dev = 0;
         hipDeviceProp_t prop;
