@@ -12,7 +12,8 @@ TFRecord/JPEG input pipeline is out of the hot-path scope: batch
 [N,H,W,3] + the six tensors of utils.data.transform_labels) or decoded images with raw boxes (images,
 objects_class [total], objects_coord [total,4] pixels, objects_first [N+1]); the latter goes through the on-device
 input pipeline (utils/augment.py: crop / resize / colour augmentation per config.ini [data_augmentation_*], labels
-built on the GPU) -- the counterpart of the reference's load_image_labels after JPEG decode."""
+built on the GPU) -- the counterpart of the reference's load_image_labels after JPEG decode.  ``--data cache`` reads the
+reference's own TFRecord cache (<cachedir>/<profile>.tfrecord for every ``-p`` profile, utils/tfrecord.py) into HBM."""
 import argparse
 import configparser
 import logging
@@ -48,7 +49,7 @@ def make_args():
     parser.add_argument('--level', help='logging level')
     parser.add_argument('--master', default='', help='accepted for compatibility (rendezvous comes from torch.distributed.run)')
     parser.add_argument('--task', type=int, default=0, help='accepted for compatibility (rank comes from RANK)')
-    parser.add_argument('--data', default='synthetic', help="'synthetic' or a .npz file")
+    parser.add_argument('--data', default='synthetic', help="'synthetic', 'cache' (the reference's TFRecord cache of -p profiles) or a .npz file")
     parser.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='overrides [mi355x] dtype')
     return parser.parse_args()
 
@@ -88,9 +89,12 @@ class DeviceAugmentedData(object):
 
     def __init__(self, z, batch, width, height, classes, cell_width, cell_height, config, seed, rank, world, session):
         from yolo_tf_amd.utils.augment import DeviceInputPipeline
-        images = list(z['images'])
-        first = z['objects_first']
-        objects = [(z['objects_class'][first[i]:first[i + 1]], z['objects_coord'][first[i]:first[i + 1]]) for i in range(len(images))]
+        if isinstance(z, tuple):          # (images, objects) already decoded, e.g. from the reference's TFRecord cache
+            images, objects = z
+        else:
+            images = list(z['images'])
+            first = z['objects_first']
+            objects = [(z['objects_class'][first[i]:first[i + 1]], z['objects_coord'][first[i]:first[i + 1]]) for i in range(len(images))]
         self.pipe = DeviceInputPipeline(images, objects, batch, width, height, classes, cell_width, cell_height, config=config,
                                         seed=seed, rank=rank, world=world)
         self.session = session
@@ -133,6 +137,14 @@ def main():
     logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
     if args.data == 'synthetic':
         data = SyntheticData(args.batch_size, len(builder.names), width, height, cell_width, cell_height, seed * world + rank + 1)
+    elif args.data == 'cache':
+        # the reference's own dataset cache: <cachedir>/<profile>.tfrecord written by its cache.py (train.py:98-100 there)
+        from yolo_tf_amd.utils import tfrecord
+        cachedir = utils.get_cachedir(config)
+        paths = [os.path.join(cachedir, profile + '.tfrecord') for profile in args.profile]
+        logging.warning('loading ' + ', '.join(paths))
+        data = DeviceAugmentedData(tfrecord.load_dataset(paths), args.batch_size, width, height, len(builder.names), cell_width, cell_height,
+                                   config, seed, rank, world, session)
     elif 'objects_coord' in np.load(args.data, allow_pickle=True).files:
         data = DeviceAugmentedData(np.load(args.data, allow_pickle=True), args.batch_size, width, height, len(builder.names), cell_width, cell_height,
                                    config, seed, rank, world, session)
