@@ -32,12 +32,13 @@ import torch         # noqa: E402
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 F32_MATRIX_PEAK_TFLOPS = 157.3
-# Fabric bytes per launch of the dominant kernel: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over this
-# same command (scripts/gpu_traffic.sh), FETCH doubled per the guide's gfx950 note, WRITE calibrated 1.00 on bn_leaky_kernel;
-# average over the 37 launches of one step (profiles/r01_hbm_traffic_pmc_final.md: 68.5 MB fetched + 21.8 MB written).  The
-# counters sit between L2 and the fabric: Infinity-Cache hits are included.  Algorithmic bytes (operands once): 27.5 MB.
-IGEMM_HBM_BYTES_PER_LAUNCH = 90.3e6
-IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 27.5e6
+# Fabric bytes per launch of the dominant kernel (the 24 3x3 launches of one step): rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# in separate passes over this same command (scripts/gpu_traffic.sh), FETCH doubled per the guide's gfx950 note, WRITE calibrated
+# 1.00 on bn_leaky_kernel (profiles/r01_hbm_traffic_pmc_final.md: 99.1 MB fetched + 27.2 MB written per launch).  The counters
+# sit between L2 and the fabric: Infinity-Cache hits are included (the 3072-channel layer alone re-reads its filter slab from
+# the MALL 11 times: 0.8 GB).  Algorithmic bytes (every operand once): 31.9 MB, 40.4 GFLOP per launch.
+IGEMM_HBM_BYTES_PER_LAUNCH = 126.3e6
+IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 31.9e6
 TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
 
 
@@ -69,7 +70,8 @@ class KernelTimer(object):
         self._cur = None
 
     def summary(self, tag=None):
-        sel = [i for i in range(len(self.pairs)) if tag is None or self.tags[i] == tag]
+        tags = None if tag is None else (tag if isinstance(tag, tuple) else (tag,))
+        sel = [i for i in range(len(self.pairs)) if tags is None or self.tags[i] in tags]
         if not sel:
             return None
         ms = [self.pairs[i][0].elapsed_time(self.pairs[i][1]) for i in sel]
@@ -211,17 +213,19 @@ def main():
             'whole_step_frac_of_mfma_peak': value * gflop / 1e3 / peak / world,
             'total_loss': loss['total_loss'],
         }
-        ks = timer.summary() if timer else None
+        ks = timer.summary(('fwd', 'dgrad')) if timer else None       # the 3x3 launches of the implicit-GEMM kernel
         if ks:
-            kf, kd = timer.summary('fwd'), timer.summary('dgrad')
+            kf, kd, k1 = timer.summary('fwd'), timer.summary('dgrad'), timer.summary('1x1')
             out['roofline'] = {'bound': 'mfma', 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak,
                                'traffic': IGEMM_HBM_BYTES_PER_LAUNCH if (args.dtype == 'bf16' and args.batch == 16 and args.size == 416) else None,
-                               'kernel': 'conv_igemm_kernel<%s,...> (implicit-GEMM forward + data-gradient convolutions with > 64 filters)' % args.dtype,
+                               'kernel': 'conv_igemm_kernel<%s, KS=3, ...> (3x3 implicit-GEMM forward + data-gradient convolutions with > 64 filters: '
+                                         'the "3x3 convs" of the north-star target)' % args.dtype,
                                'launches': ks['launches'], 'avg_launch_ms': ks['avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
                                'algorithmic_bytes_per_launch': IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH, 'traffic_unit': 'bytes per launch (PMC, separate passes)',
                                'measured_over': '%d instrumented single-stream training steps run right after the timed region '
                                                 '(events inside it cost 11 %% of the step)' % min(args.steps, 10),
-                               'forward_launches_tflops': kf['tflops'] if kf else None, 'data_gradient_launches_tflops': kd['tflops'] if kd else None}
+                               'forward_launches_tflops': kf['tflops'] if kf else None, 'data_gradient_launches_tflops': kd['tflops'] if kd else None,
+                               'one_by_one_launches_same_template': {'tflops': k1['tflops'], 'launches': k1['launches'], 'avg_launch_ms': k1['avg_ms']} if k1 else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.names, args.size)
         if world == 1 and not args.no_detect:

@@ -190,12 +190,13 @@ class Engine(object):
 
     # ---------------------------------------------------------------- helpers
     def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k, bn_shift=None):
-        """yolo2_conv2d launch; when a timer is attached, launches that take the 128-wide filter tile
-        (Nf > 64: the kernel that carries ~2/3 of the training FLOPs) are bracketed by HIP events.
+        """yolo2_conv2d launch; when a timer is attached, the 3x3 launches that take the 128-wide filter tile (Nf > 64:
+        conv_igemm_kernel<.., KS = 3, ..>, the kernel that carries 64 % of the training FLOPs; the filter gradient carries
+        most of the rest) are bracketed by HIP events; the 1x1 launches are tagged separately.
         ``real_k`` = unpadded reduction length, for the algorithmic FLOP count."""
         t = self.kernel_timer if Nf > 64 else None
         if t is not None:
-            t.start(2.0 * self.B * H * W * Nf * real_k, self._phase)
+            t.start(2.0 * self.B * H * W * Nf * real_k, self._phase if k == 3 else '1x1')
         if bn_shift is not None:     # training forward of a batch-normalised layer: statistics from the conv epilogue
             ops.conv2d_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, bn_shift, self.bn_part)
         else:
