@@ -304,6 +304,10 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
         ks = cdiv(target, p.tiles);
         if (ks > max_ks) ks = max_ks;
     }
+    // a tile grid that already covers the chip takes ONE pixel range: no atomics, plain stores (measured: the atomic epilogue
+    // of a 2-way split costs more than the second workgroup per tile gains)
+    static const int direct_min = getenv("YOLO2_WGRAD_DIRECT_MIN_TILES") ? atoi(getenv("YOLO2_WGRAD_DIRECT_MIN_TILES")) : 256;
+    if (direct_min > 0 && p.tiles >= direct_min) { ks = 1; remap = 0; }
     if (ks < 1) ks = 1;
     p.mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
     ks = cdiv(M, p.mchunk);
