@@ -291,7 +291,10 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
     static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
     const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
-    int target = env_target > 0 ? env_target : (BC >= 128 ? 512 : 1024);
+    // 64-wide tile: ~1024 blocks for the 3x3 layers, ~384 for the 1x1 layers (9x fewer tiles: more, shorter pixel ranges only add
+    // atomic traffic; measured 19.6 -> 15.3 us on the 26x26 1x1 layers)
+    const int def_target = BC >= 128 ? 512 : (ksize == 1 ? 384 : 1024);
+    int target = env_target > 0 ? env_target : def_target;
     int ks = cdiv(target, p.tiles);
     int remap = env_remap >= 0 ? env_remap : (ks >= 8 && max_ks >= 8);
     if (remap) {
@@ -300,7 +303,7 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
         if (ks < 8) remap = 0;
     }
     if (!remap) {
-        if (env_target <= 0) target = BC >= 128 ? 512 : 1024;
+        if (env_target <= 0) target = def_target;
         ks = cdiv(target, p.tiles);
         if (ks > max_ks) ks = max_ks;
     }
