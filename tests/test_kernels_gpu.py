@@ -668,3 +668,21 @@ def test_optimizers_vs_oracle(ops):
     torch.cuda.synchronize()
     ref = np.concatenate([R.clip_by_norm(g[seg[i]:seg[i + 1]], 5.0) for i in range(3)])
     assert_close(host(gd), ref, 1e-6, 'clip_by_norm')
+
+
+def test_optimizer_slice_updates_equal_whole_arena_update(ops):
+    """Optimizer.apply(lo, hi): updating the arena bucket by bucket (data-parallel path) is bit-identical to one launch."""
+    from yolo_tf_amd.optim import Optimizer
+    n = 10007 * 4
+    rng = np.random.RandomState(0)
+    p0, g0 = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    outs = []
+    for cuts in ([0, n], [0, 4096, 20000, 20004, n]):
+        opt = Optimizer('adam', None, n, torch.device('cuda'))
+        p, g = dev(p0.copy()), dev(g0.copy())
+        for t in (1, 2, 3):
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                opt.apply(p, g, 1e-3, t, 0.5, lo, hi)
+        torch.cuda.synchronize()
+        outs.append(host(p))
+    np.testing.assert_array_equal(outs[0], outs[1])

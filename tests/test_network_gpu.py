@@ -267,7 +267,11 @@ def _dp_worker(rank, world, port, outdir):
     summed = e.grads.clone()
     sess.apply_gradients()
     torch.cuda.synchronize()
-    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), local=local.cpu().numpy(), summed=summed.cpu().numpy(), params=e.params.cpu().numpy())
+    params1 = e.params.clone()
+    sess.step(images)                                   # the production path: buckets consumed by the optimizer as they arrive
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), local=local.cpu().numpy(), summed=summed.cpu().numpy(), params=params1.cpu().numpy(),
+             params2=e.params.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -287,4 +291,6 @@ def test_data_parallel_step_two_processes_one_gpu(tmp_path):
     ref = r0['local'] + r1['local']
     assert np.abs(r0['summed'] - ref).max() <= 1e-5 * np.abs(ref).max()      # f32 atomics: order-dependent rounding only
     np.testing.assert_array_equal(r0['params'], r1['params'])
+    np.testing.assert_array_equal(r0['params2'], r1['params2'])                 # bucket-wise update: replicas still identical
+    assert np.abs(r0['params2'] - r0['params']).max() > 0
     assert np.abs(r0['local'] - r1['local']).max() > 0                          # the ranks really saw different data

@@ -87,6 +87,15 @@ def _worker(rank, world, port, out):
         red.finish()
         expect = torch.arange(off, dtype=torch.float32) * sum(range(1, world + 1))
         assert torch.equal(grads, expect), (rank, step)
+    # deferred consumption: finish(wait=False) + completed_buckets() hands the buckets over one by one, each already summed
+    grads.copy_(torch.arange(off, dtype=torch.float32) * (rank + 1))
+    red.begin()
+    red.finish(wait=False)
+    seen = []
+    for lo, hi in red.completed_buckets():
+        assert torch.equal(grads[lo:hi], torch.arange(lo, hi, dtype=torch.float32) * sum(range(1, world + 1))), (rank, lo, hi)
+        seen.append((lo, hi))
+    assert seen == red.buckets
     # folded averaging: the optimizer's gscale = 1/world turns the sum into the mean
     assert torch.allclose(grads / world, torch.arange(off, dtype=torch.float32) * (world + 1) / 2)
     if rank == 0:

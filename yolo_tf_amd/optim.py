@@ -58,9 +58,15 @@ class Optimizer(object):
             'gd': lambda: [],
         }[name]()
 
-    def apply(self, params, grads, lr, t, gscale=1.0):
-        """t = 1-based update count (Adam bias correction)."""
-        hp, n, s = self.hp, self.n, self.slots
+    def apply(self, params, grads, lr, t, gscale=1.0, lo=0, hi=None):
+        """t = 1-based update count (Adam bias correction).  [lo, hi) restricts the update to a slice of the flat arenas
+        (data parallel: one call per all-reduce bucket as the buckets arrive)."""
+        hp = self.hp
+        hi = self.n if hi is None else hi
+        n = hi - lo
+        if lo != 0 or hi != self.n:
+            params, grads = params[lo:hi], grads[lo:hi]
+        s = [slot[lo:hi] for slot in self.slots] if (lo != 0 or hi != self.n) else self.slots
         if self.name == 'adam':
             alpha = lr * math.sqrt(1.0 - hp['beta2'] ** t) / (1.0 - hp['beta1'] ** t)
             ops.adam(params, grads, s[0], s[1], n, alpha, hp['beta1'], hp['beta2'], hp['epsilon'], gscale)

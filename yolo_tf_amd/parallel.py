@@ -57,11 +57,13 @@ class GradReducer(object):
         self.next_bucket = 0
         self.handles = []
         self.pending_events = []
+        self.done_events = []
 
     def begin(self):
         self.next_bucket = 0
         self.handles = []
         self.pending_events = []
+        self.done_events = []        # per launched bucket: completes when its all-reduce has (CUDA path)
 
     def ready_upto(self, end_offset, event=None):
         """Backward has enqueued every gradient in [0, end_offset): launch the complete buckets.  ``event`` (optional)
@@ -86,16 +88,34 @@ class GradReducer(object):
             self.pending_events = []
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+            self.done_events.append(done)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
-        """Flushes the remaining buckets and makes the compute stream wait for the collectives."""
+    def finish(self, wait=True):
+        """Flushes the remaining buckets; with ``wait`` the compute stream then waits for every collective.  With
+        wait=False the caller consumes the buckets one by one through ``completed_buckets()`` (the optimizer updates bucket k
+        while buckets k+1.. are still on the wire)."""
         if self.world == 1:
             return
         self.ready_upto(self.grads.numel())
+        if not wait:
+            return
         if self.use_stream:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
         else:
             for h in self.handles:
                 h.wait()
+
+    def completed_buckets(self):
+        """Yields (start, end) of every bucket in launch order, each after making the current stream (or the host, on the CPU
+        path) wait for that bucket's all-reduce only."""
+        for i, (s, e) in enumerate(self.buckets):
+            if self.world > 1:
+                if self.use_stream:
+                    torch.cuda.current_stream().wait_event(self.done_events[i])
+                else:
+                    self.handles[i].wait()
+            yield s, e

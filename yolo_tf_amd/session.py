@@ -1,5 +1,7 @@
 """Training / detection sessions: the counterpart of what the reference's callers drive through
 ``slim.learning.train`` (train.py:109-145) and ``sess.run`` (detect.py:69-71)."""
+import os
+
 import numpy as np
 import torch
 
@@ -44,6 +46,7 @@ class TrainSession(object):
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
         self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb) if world_size > 1 else None
+        self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
 
@@ -51,7 +54,9 @@ class TrainSession(object):
         for dst, src in zip(self.labels, labels):
             dst.copy_(torch.from_numpy(np.ascontiguousarray(src, np.float32).reshape(dst.shape)), non_blocking=True)
 
-    def forward_backward(self, images):
+    def forward_backward(self, images, defer_collectives=False):
+        """Gradients are final (all-reduced) on return unless ``defer_collectives``: then the buckets may still be on the wire
+        and ``apply_gradients`` consumes them one by one (what ``step`` does)."""
         e, m = self.engine, self.model
         e.zero_grads()
         e.set_images(images, self.preprocess_mode)
@@ -64,7 +69,9 @@ class TrainSession(object):
         if self.reducer is not None:
             self.reducer.begin()
             e.backward(on_layer_done=lambda op, ev: self.reducer.ready_upto(self._layer_end[op['name']], ev))
-            self.reducer.finish()
+            # without clipping the optimizer consumes the buckets as they arrive (apply_gradients); clipping needs them all
+            self._deferred = defer_collectives and self.gradient_clip <= 0 and self.bucketed_update
+            self.reducer.finish(wait=not self._deferred)
         else:
             e.backward()
 
@@ -79,14 +86,21 @@ class TrainSession(object):
         else:
             gscale = 1.0 / self.world_size
         lr = self.lr_fn(self.global_step)
-        self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale)
+        if self.reducer is not None and getattr(self, '_deferred', False):
+            # data parallel: update bucket k while the all-reduces of buckets k+1.. are still in flight -- only the last
+            # (smallest: the early layers) bucket's collective is exposed, and the 1.9 GB optimizer pass hides the rest
+            for lo, hi in self.reducer.completed_buckets():
+                self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale, lo, hi)
+            self._deferred = False
+        else:
+            self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale)
         self.global_step += 1
         e._filters_dirty = True
 
     def step(self, images, labels=None):
         if labels is not None:
             self.upload_labels(labels)
-        self.forward_backward(images)
+        self.forward_backward(images, defer_collectives=True)
         self.apply_gradients()
 
     def fetch(self):
