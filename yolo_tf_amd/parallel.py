@@ -53,7 +53,8 @@ class GradReducer(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.buckets = make_buckets(offsets_sizes, grads.numel(), int(bucket_mb * 1024 * 1024 / 4))
         self.use_stream = grads.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.use_stream else None
+        # high priority: a bucket's collective should start as soon as its gradients are final, not queue behind backward kernels
+        self.comm_stream = torch.cuda.Stream(priority=-1) if self.use_stream else None
         self.next_bucket = 0
         self.handles = []
         self.pending_events = []
