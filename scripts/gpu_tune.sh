@@ -1,8 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 : > gpurun_out/tune.log
-YOLO2_IGEMM_SMALL_BM256=1 timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "conv_forward or conv_dgrad" < /dev/null 2>&1 | tail -2 | tee -a gpurun_out/tune.log
-for cfg in "YOLO2_IGEMM_SMALL_BM256=0" "YOLO2_IGEMM_SMALL_BM256=1"; do
-  env $cfg timeout 200 python scripts/conv_bench.py "$cfg" 2>/dev/null < /dev/null | grep -v amdgpu.ids >> gpurun_out/tune.log
-done
+timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" < /dev/null 2>&1 | tail -3 | tee -a gpurun_out/tune.log
+timeout 200 python scripts/conv_bench.py "tap pairing" 2>/dev/null < /dev/null | grep -v amdgpu.ids >> gpurun_out/tune.log
 cat gpurun_out/tune.log

@@ -30,7 +30,9 @@
 
 #define Y2_OOB 0x80000000u
 
-template <typename T, int BC, int BNN, int VARIANT, int NW = 4, int BKPv = 0>
+// PAIR (BC = 64, Cin <= 32): the 64 tile rows hold TWO taps x 32 channels (rows 0-31: tap 2p, rows 32-63: tap 2p+1), so a
+// 32-channel layer (conv1: 25 GFLOP) does not spend half of every MFMA on zero rows.
+template <typename T, int BC, int BNN, int VARIANT, int NW = 4, int BKPv = 0, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W,
     int Cin, int ldx, int Cout, int ldy, int ksize, int M, int CT, int NT, int mchunk, int remap, int direct) {
@@ -62,7 +64,9 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     // rows, so they are placed on ONE XCD (the dispatcher puts block b on XCD b % 8; observed, speed only):
     // XCD x walks the pixel ranges y = x, x+8, ... and for each runs all tiles back to back, which keeps a
     // range's rows in that XCD's private L2 instead of fetching them into up to 8 L2s.
-    const int ntiles = ksize * ksize * CT * NT;
+    const int taps = ksize * ksize;
+    const int tgroups = PAIR ? (taps + 1) / 2 : taps;         // tile rows along the tap axis
+    const int ntiles = tgroups * CT * NT;
     int bx, by;
     if (remap) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -74,9 +78,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     }
     const int nt = bx % NT; bx /= NT;
     const int ct = bx % CT;
-    const int tap = bx / CT;
+    const int tap = PAIR ? 2 * (bx / CT) : bx / CT;            // PAIR: first tap of the pair
     const int pad = ksize >> 1;
     const int dh = tap / ksize - pad, dw = tap % ksize - pad;
+    const int tap2 = tap + 1;                                  // PAIR: second tap (may not exist: taps is odd)
+    const int dh2 = tap2 / ksize - pad, dw2 = tap2 % ksize - pad;
     const int c0 = ct * BC, n0 = nt * BNN;
     const int mbeg = by * mchunk;
     const int mend = min(M, mbeg + mchunk);
@@ -91,12 +97,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const double rcp_hw = 1.0 / (double)(H * W);
     const float rcp_w = 1.0f / (float)W;
     unsigned x_voff[X_IT], y_voff[Y_IT];
-    int xh[X_IT], xw[X_IT];
+    int xh[X_IT], xw[X_IT], ldh[X_IT], ldw[X_IT];
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
         const int r = (wave * X_IT + i) * XRPI + lane / XCH;                 // pixel row inside the tile
         const int chunk = (lane % XCH) ^ (((r / XRPL) % XSWM) * 4);          // source-side swizzle
-        const int c = c0 + chunk * VEC;
+        const bool second = PAIR && chunk * VEC >= 32;                       // this lane's chunk belongs to the pair's second tap
+        const int c = PAIR ? (chunk * VEC) & 31 : c0 + chunk * VEC;
+        ldh[i] = second ? dh2 : dh;
+        ldw[i] = second ? dw2 : dw;
         const int m = mbeg + r;
         // (h, w) of pixel m without integer division (see conv_igemm.hip): reciprocal estimate + one correction step
         const int HW = H * W;
@@ -105,10 +114,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         int hh = (int)((float)rem * rcp_w);
         int ww = rem - hh * W;
         if (ww < 0) { ww += W; --hh; } else if (ww >= W) { ww -= W; ++hh; }
-        xh[i] = hh + dh;                                                     // shifted coordinates of this row's pixel
-        xw[i] = ww + dw;
-        // channel chunk beyond Cin (or beyond the padded pixel stride): permanently out of range
-        x_voff[i] = (c < Cin && c < ldx) ? (unsigned)((long)(m + dh * W + dw) * ldx + c) * (unsigned)sizeof(T) : Y2_OOB;
+        xh[i] = hh + ldh[i];                                                 // shifted coordinates of this row's pixel
+        xw[i] = ww + ldw[i];
+        // channel chunk beyond Cin (or beyond the padded pixel stride, or a pair's missing second tap): permanently out of range
+        x_voff[i] = (c < Cin && c < ldx && !(second && tap2 >= taps))
+                        ? (unsigned)((long)(m + ldh[i] * W + ldw[i]) * ldx + c) * (unsigned)sizeof(T) : Y2_OOB;
     }
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
@@ -144,10 +154,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
             x_voff[i] += x_step;           // OOB + k*step stays >= 2^31 for every step taken (operands < 2^31 bytes)
             xw[i] += adv_w;                 // BKP pixels further = adv_h rows + adv_w columns (branch-free: this runs per DMA piece)
             xh[i] += adv_h;
-            const bool wrap = xw[i] - dw >= W;
+            const bool wrap = xw[i] - ldw[i] >= W;
             xw[i] -= wrap ? W : 0;
             xh[i] += wrap ? 1 : 0;
-            xh[i] -= (xh[i] - dh >= H) ? H : 0;
+            xh[i] -= (xh[i] - ldh[i] >= H) ? H : 0;
         }
 #pragma unroll
         for (int i = 0; i < Y_IT; ++i) {
@@ -249,7 +259,10 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     }
 
     // epilogue: rows = input channels c, cols = filters n; dW is HWIO [tap][Cin][Cout]
-    float *out = dW + (long)tap * Cin * Cout;
+    // PAIR: WGM = 2 and TM = 1, so wave row wm holds exactly one tap of the pair (rows 32*wm .. 32*wm+31 = its 32 channels)
+    const int my_tap = PAIR ? tap + wm : tap;
+    if (PAIR && my_tap >= taps) return;
+    float *out = dW + (long)my_tap * Cin * Cout;
     auto write_tile = [&](auto checked_tag) {      // interior tiles skip the per-element channel tests (a branch each)
         constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
             if (CHECKED && n >= Cout) continue;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int cb = c0 + (wm * TM + i) * 32 + 4 * (lane >> 5);
+                const int cb = (PAIR ? 0 : c0 + (wm * TM + i) * 32) + 4 * (lane >> 5);
                 float *col = out + (long)cb * Cout + n;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
             }
         }
     };
-    if (c0 + BC <= Cin && n0 + BNN <= Cout) write_tile(std::false_type{});
+    if ((PAIR ? Cin == 32 : c0 + BC <= Cin) && n0 + BNN <= Cout) write_tile(std::false_type{});
     else write_tile(std::true_type{});
 }
 
@@ -284,10 +297,13 @@ struct WgradPlan { int tiles, ks, remap, mchunk, blocks; };
 // (profiles/r01_wgrad_mapping_ab.txt): with >= 8 ranges the XCD-local placement wins (+35..45 %) at ~512
 // blocks for the 128-wide tile / ~1024 for the 64-wide one; with fewer ranges (13x13 stages) it would
 // leave XCDs idle, so those keep the plain mapping (~512 blocks of 8 waves for the 128-wide tile).
+static bool wgrad_pairs_taps(int Cin, int ksize) { return ksize == 3 && Cin <= 32 && g_wgrad_variant == 0; }     // 64-row tile = two taps x 32 channels
+
 static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN, int BKP) {
     WgradPlan p;
     const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
-    p.tiles = ksize * ksize * CT * NT;
+    const int tgroups = (BC == 64 && wgrad_pairs_taps(Cin, ksize)) ? (ksize * ksize + 1) / 2 : ksize * ksize;
+    p.tiles = tgroups * CT * NT;
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
     static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
     const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
@@ -336,6 +352,12 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     if constexpr (BC >= 128) {
         if (g_wgrad_variant == 0 && nw8) {
             conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
+            return;
+        }
+    }
+    if constexpr (BC == 64) {
+        if (g_wgrad_variant == 0 && wgrad_pairs_taps(Cin, ksize)) {
+            conv_wgrad_kernel<T, BC, BNN, 0, 4, 0, true><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
             return;
         }
     }
