@@ -243,6 +243,18 @@ int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, doub
  * fills out[64*4] with the raw result of ds_read_b64_tr_b16 over a 0..N ramp (layout self-test) */
 int yolo2_selftest_tr16(short *out, void *stream);
 
+/* Whole backward of the image layer -- conv(3 channels in an 8-wide pixel, 32 filters, no dX needed) -> batch norm -> leaky
+ * -> 2x2/2 max pool (model/yolo2/inference.py:73-74 under tf.gradients) -- in ONE pass over (X, Y, dP, idx): equals
+ * yolo2_bn_leaky_pool_bwd_reduce + _apply + yolo2_conv2d_wgrad, but dY (177 MB at batch 16) is never formed: the filter
+ * gradient is evaluated in closed form from sum xs*g, sum xs*y, sum xs and the two BN sums (derivation in
+ * csrc/conv_first.hip).  X [B,H,W,8], Y [B,H,W,32] (raw conv output), dP [B,H/2,W/2,32], idx from yolo2_bn_leaky_pool;
+ * dW [3,3,Cin,32] f32 is OVERWRITTEN.  scratch: >= YOLO2_IMAGE_LAYER_BWD_SCRATCH floats, all zero on entry, left zero.
+ * bf16 only. */
+#define YOLO2_IMAGE_LAYER_BWD_SCRATCH 8192
+int yolo2_image_layer_bwd(const void *X, const void *Y, const void *dP, const unsigned char *idx, const float *mean, const float *var,
+                          const float *gamma, const float *beta, float *dgamma, float *dbeta, float *dW, float *scratch, int B,
+                          int H, int W, int Cin, float eps, float alpha, int dtype, void *stream);
+
 /* ---- on-device input pipeline: utils/data/__init__.py:50-109,162-175 + utils/preprocess.py:28-71 after JPEG
  * decode.  `src` holds the decoded uint8 RGB images back to back (any sizes); per image the caller supplies the
  * outcome of every random draw of the reference (tf.random_uniform / tf.cond):

@@ -9,6 +9,6 @@ while IFS= read -r cfg; do
     echo "$cfg rep$rep: $v" | tee -a gpurun_out/ab.log
   done
 done <<CFG
-YOLO2_COLSUM_BLOCKS=0
-YOLO2_COLSUM_BLOCKS=256
+YOLO2_FUSE_IMAGE_BWD=1
+YOLO2_FUSE_IMAGE_BWD=0
 CFG

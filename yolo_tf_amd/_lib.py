@@ -36,6 +36,7 @@ SIGNATURES = {
     'yolo2_bn_leaky_pool': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
+    'yolo2_image_layer_bwd': [_p] * 12 + [_i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_augment_images': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     'yolo2_transform_labels': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],

@@ -173,6 +173,10 @@ class Engine(object):
                         self.conv[producers[x]['name']]['pool_idx'] = torch.zeros(B * (x.h // 2) * (x.w // 2) * x.c, dtype=torch.uint8, device=dev)
         # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
         # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
+        # off by default: correct (tests/test_kernels_gpu.py::test_image_layer_backward_fused) but measured 0.27 ms SLOWER per
+        # step than the three unfused kernels -- 316 VGPRs leave one wave per SIMD for a pass that is mostly per-element VALU work
+        self.fuse_image_bwd = os.environ.get('YOLO2_FUSE_IMAGE_BWD', '0') != '0'
+        self.image_bwd_scratch = torch.zeros(8192, dtype=torch.float32, device=dev)    # YOLO2_IMAGE_LAYER_BWD_SCRATCH, kept zero
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
         self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
@@ -387,6 +391,15 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     dgam, dbet = self.gvar[op['gamma'].name], self.gvar[op['beta'].name]
                     pool = self.fused_pool.get(out)
+                    if (pool is not None and x in inputs and self.fuse_image_bwd and self.dtype == torch.bfloat16 and k == 3 and cout == 32
+                            and ldx == 8 and self.gact[pool['out']][1] == 32):
+                        # image layer: no dX is needed, so BN/leaky/pool backward AND the filter gradient collapse into one pass
+                        # over (x, y, dP, idx) -- dY is never formed (yolo2_image_layer_bwd)
+                        ops.image_layer_bwd(xb, yb, self.gact[pool['out']][0], st['pool_idx'], st['mean'], st['var'], gamma, beta, dgam, dbet,
+                                            self.gvar[op['weights'].name], self.image_bwd_scratch, B, x.h, x.w, op['cin'], BN_EPS, LEAKY_ALPHA)
+                        if on_layer_done is not None:
+                            on_layer_done(op, None)
+                        continue
                     if pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
                         dpb, lddp = self.gact[pool['out']]
                         ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,

@@ -201,3 +201,8 @@ def transform_labels(objects_class, objects_coord, first_object, mask, prob, coo
                      cell_width, cell_height, error_flag):
     call('yolo2_transform_labels', ptr(objects_class), ptr(objects_coord), ptr(first_object), ptr(mask), ptr(prob), ptr(coords),
          ptr(offset_xy_min), ptr(offset_xy_max), ptr(areas), B, classes, cell_width, cell_height, ptr(error_flag), _stream())
+
+
+def image_layer_bwd(X, Y, dP, idx, mean, var, gamma, beta, dgamma, dbeta, dW, scratch, B, H, W, Cin, eps, alpha):
+    call('yolo2_image_layer_bwd', ptr(X), ptr(Y), ptr(dP), ptr(idx), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
+         ptr(dW), ptr(scratch), B, H, W, Cin, eps, alpha, dtype_code(X.dtype), _stream())
