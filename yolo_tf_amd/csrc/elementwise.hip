@@ -1253,7 +1253,16 @@ extern "C" int yolo2_bn_leaky_pool_bwd_reduce(const void *dP, int lddp, const un
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     hipStream_t st = (hipStream_t)stream;
     const long MP = (long)B * (H / 2) * (W / 2);
-    const int nb = colsum_grid(MP, C, vec);
+    int nb = colsum_grid(MP, C, vec);
+    // the 416x416 / 208x208 stages (> 64 MB of conv output): one workgroup per CU is latency-bound at 3 TB/s (measured 80 -> 62 us
+    // with four); smaller tensors keep the short finalisation
+    static const int big = getenv("YOLO2_POOL_REDUCE_BLOCKS") ? atoi(getenv("YOLO2_POOL_REDUCE_BLOCKS")) : 1024;
+    if (big > nb && (long)B * H * W * C * (16 / vec) >= (64L << 20)) {
+        const int tpr = C / vec, rpp = 256 / tpr < 1 ? 1 : 256 / tpr;
+        long g = (MP + (long)rpp * 4 - 1) / ((long)rpp * 4);
+        nb = (int)(g < big ? g : big);
+        if (nb > 1024) nb = 1024;
+    }
     float *part = (float *)ws;
     Y2_DISPATCH_DTYPE(dtype, bn_pool_bwd_reduce_kernel<T><<<nb, 256, 0, st>>>((const T *)dP, lddp, idx, (const T *)Y, mean, var, gamma, beta, part, B, H, W, C, eps, alpha));
     reduce_finalize_kernel<1><<<cdiv(C, 16), 256, 0, st>>>(part, nb, C, (long)B * H * W, dgamma, dbeta, C);
