@@ -6,27 +6,39 @@
 //   O[m, n] = bias[n] + sum_{tap, c} P[pix(m) + shift(tap), c] * F[n][tap*Cp + c]
 //   GEMM view: M = B*H*W output pixels, N = Nf filters, K = ksize^2 * Cp.
 //
-// Structure (one workgroup = 4 waves = a 128(M) x BN(N) output tile, K step = 64 bytes of channels of
-// one tap):
+//   K order of a filter row: 64-channel chunk, tap, channel (common.h y2_filter_koff): the 9 shifted re-reads of a
+//   pixel-tile x 64-channel slab are consecutive K steps and hit in the XCD's L2.
+//
+// Structure (one workgroup = NW waves = a BM(M) x BN(N) output tile; a K step = CH 16-byte chunks of one tap's channels):
 //   * Operands go HBM/L2 -> LDS by DMA: buffer_load_dwordx4 ... lds (1 KiB per wave-instruction, no
 //     VGPR round trip, no ds_write pass).  The DMA writes LDS lane-linearly (wave-uniform base +
 //     lane*16 B), so rows cannot be padded; the b128 fragment reads are kept bank-conflict-free by an
 //     XOR swizzle applied on the SOURCE side: the lane that owns LDS position (row, slot) fetches global
-//     chunk  slot ^ ((row / rows_per_256B) % 4); the fragment reads apply the same involution
+//     chunk  slot ^ ((row / rows_per_256B) % CH); the fragment reads apply the same involution
 //     (SQ_LDS_BANK_CONFLICT = 0 measured).
 //   * SAME padding, image borders, the M tail, filter-row tail and channel tail are all realised by the
 //     buffer descriptor's hardware range check: a lane that must contribute zeros uses an out-of-range
 //     offset and the DMA writes 0 -- no branches, no pointer selects, 32-bit offsets only.  Which of the
-//     9 taps are inside the image for a pixel row is a 9-bit mask computed once per lane.
-//     (The first version computed bounds + 64-bit addresses + tap/ksize divisions per DMA piece and spent
-//     11 VALU + 12 SALU instructions per MFMA: instruction-issue bound at 17 % MFMA utilisation.)
+//     9 taps are inside the image for a pixel row is a 9-bit mask (outer product of a row and a column 3-bit set)
+//     computed once per lane per tile, with reciprocal-multiply pixel decoding (no hardware integer divider).
+//     Instruction overhead per MFMA decided the short-reduction layers twice: the first version spent 11 VALU + 12 SALU
+//     per MFMA on per-piece address arithmetic (17 % MFMA utilisation); later the tile prologue's divisions and the
+//     per-element row test of the epilogue cost conv1..conv8 15-35 %.
 //   * NSTAGE-deep LDS ring: the DMA of tile t+NSTAGE-1 is issued right after the barrier of tile t and
 //     only tile t's own pieces are waited for (counted s_waitcnt vmcnt(N) + raw s_barrier; a
 //     __syncthreads() would drain every DMA in flight).
 //   * A = pixels (rows), B = filters (cols): the 32x32 accumulator layout puts 32 consecutive output
 //     channels of one pixel in 32 consecutive lanes -> 64 B (bf16) / 128 B (f32) store segments.
-//   * Small M x N grids (13x13 / 26x26 stages at batch 16) slice the K loop over gridDim.y; partial
-//     tiles are accumulated in an f32 workspace with hardware atomics and finished by a tiny kernel.
+//   * Shapes (chosen per layer from measurements, launch_conv below): 128x128 tile, 8 waves, 128-byte K rows on a 2-stage
+//     ring (64 KiB: two workgroups per CU, 8 MFMAs per wave between barriers) for full grids; 64-byte rows / 3 stages
+//     when the channel count is not a multiple of 64; 64- and 32-filter tiles for the narrow layers.
+//   * Under-filled grids (13x13 / 26x26 stages at batch 16: 88-176 tiles for 256 CUs) run stream-K: one workgroup per CU,
+//     equal contiguous shares of the flat (tile, K step) space, partial tiles parked in the workspace and fixed up by
+//     the tile's owner through sc1 (agent-coherent, fence-free) accesses -- see the SPLITK == 2 epilogue; long
+//     reductions take a 256x128 tile (8 waves of 64x64, 16 MFMAs per barrier).  Grids <= 128 tiles with a medium
+//     reduction slice the K loop over gridDim.y with f32 atomics + a finishing kernel (SPLITK == 1).
+//   * The epilogue can also emit the batch-norm partial sums of the stored outputs (yolo2_conv2d_bn) and apply
+//     bias + leaky ReLU (yolo2_conv2d_bias_leaky, BN-folded inference).
 //   * blockIdx -> tile: filter tile fastest (the blocks of XCD b%8 keep one filter slab in their L2), or,
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"
