@@ -23,7 +23,11 @@
 // measured 1.5-1.9x slower on the 13x13 / 26x26 stages: the per-DMA-piece border bookkeeping and the single resident
 // workgroup outweigh the halved LDS traffic; profiles/r01_wgrad_big_tile.txt.)
 // Grid: x = (tap, c-tile, n-tile), y = pixel-range split; partial tiles are accumulated into the
-// zero-initialised f32 dW with hardware f32 atomics (lanes run along n -> coalesced).
+// zero-initialised f32 dW with hardware f32 atomics (lanes run along n -> coalesced).  A tile grid that already covers the
+// chip takes ONE pixel range and stores instead (yolo2_conv2d_wgrad_accumulates tells the caller which arena ranges still
+// need zeroing).  Shapes: 128x128 tile with 8 waves for the wide layers, 64x64 with 4 waves for <= 64 channels / few-tile
+// layers, two taps per 64-row tile for <= 32 input channels (PAIR).  The per-DMA-piece border bookkeeping ((h, w) of every
+// staged pixel row, advanced branch-free by a constant pixel step) is the kernel's main non-MFMA cost.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
