@@ -185,3 +185,36 @@ def test_device_pipeline_feeds_a_training_step(ops, tmp_path):
         sess.step(batch)
         losses.append(sess.fetch()['total_loss'])
     assert np.all(np.isfinite(losses))
+
+
+def test_reference_cache_to_training_step(ops, tmp_path):
+    """The whole widened path: JPEGs + a TFRecord cache in the reference's schema (utils/tfrecord.py) -> HBM-resident dataset ->
+    on-device augmentation and labels -> training steps."""
+    Image = pytest.importorskip('PIL.Image')
+    import configparser
+    from test_network_gpu import make_builder
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import tfrecord
+    from yolo_tf_amd.utils.augment import DeviceInputPipeline
+    rng = np.random.RandomState(11)
+    samples = []
+    for i in range(5):
+        h, w = 60 + 9 * i, 80 + 11 * i
+        p = str(tmp_path / ('%06d.jpg' % i))
+        Image.fromarray(rng.randint(0, 256, (h, w, 3)).astype(np.uint8)).save(p, quality=90)
+        k = rng.randint(1, 4)
+        x0, y0 = rng.uniform(0, 0.5 * w, k), rng.uniform(0, 0.5 * h, k)
+        samples.append((p, (h, w, 3), rng.randint(0, 20, k), np.stack([x0, y0, x0 + rng.uniform(8, 0.4 * w, k), y0 + rng.uniform(8, 0.4 * h, k)], 1)))
+    cache = str(tmp_path / 'train.tfrecord')
+    tfrecord.write_cache(cache, samples)
+    images, objects = tfrecord.load_dataset([cache])
+    assert len(images) == 5 and images[3].shape == (87, 113, 3)
+    b, _ = make_builder('tiny', 20, 96, True, str(tmp_path / 'base'))
+    sess = TrainSession(b, 4, dtype='bf16', optimizer='adam', learning_rate=1e-3, seed=1)
+    ini = configparser.ConfigParser()
+    ini.read(os.path.join(ROOT, 'config.ini'))
+    pipe = DeviceInputPipeline(images, objects, 4, 96, 96, 20, 3, 3, config=ini, seed=5)
+    for _ in range(4):
+        sess.step(pipe.next(sess))
+        pipe.check()
+    assert np.isfinite(sess.fetch()['total_loss'])
