@@ -1091,15 +1091,40 @@ extern "C" int yolo2_image_prep(const float *img, void *out, double *ws, int B, 
 // ------------------------------------------------------------------------------------------
 #define OPT_LOOP(n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
 
-__global__ void adam_kernel(float *w, const float *g, float *m, float *v, long n, float alpha, float omb1, float omb2, float eps, float gs) {
-    OPT_LOOP(n) {
-        float gi = g[i] * gs;
-        float mi = m[i] + (gi - m[i]) * omb1;
-        float vi = v[i] + (gi * gi - v[i]) * omb2;
-        m[i] = mi;
-        v[i] = vi;
-        w[i] = w[i] - (mi * alpha) / (sqrtf(vi) + eps);
+// the dominant optimizer: 28 B of HBM traffic per parameter.  16-byte accesses when the four arenas are 16-byte aligned
+// (they are: the engine's arenas and every all-reduce bucket start on a multiple of 4 elements), scalar tail otherwise.
+__device__ __forceinline__ void adam_one(float &w, float g, float &m, float &v, float alpha, float omb1, float omb2, float eps, float gs) {
+    const float gi = g * gs;
+    const float mi = m + (gi - m) * omb1;
+    const float vi = v + (gi * gi - v) * omb2;
+    m = mi;
+    v = vi;
+    w = w - (mi * alpha) / (sqrtf(vi) + eps);
+}
+__global__ __launch_bounds__(256) void adam_kernel(float *w, const float *g, float *m, float *v, long n, float alpha, float omb1, float omb2, float eps, float gs) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    long done = 0;
+    if (((((uintptr_t)w) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
+        const long n4 = n >> 2;
+        f32x4 *w4 = reinterpret_cast<f32x4 *>(w), *m4 = reinterpret_cast<f32x4 *>(m), *v4 = reinterpret_cast<f32x4 *>(v);
+        const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g);
+        for (long k = i; k < n4; k += stride) {
+            f32x4 wv = w4[k], mv = m4[k], vv = v4[k];
+            const f32x4 gv = g4[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float wj = wv[j], mj = mv[j], vj = vv[j];
+                adam_one(wj, gv[j], mj, vj, alpha, omb1, omb2, eps, gs);
+                wv[j] = wj; mv[j] = mj; vv[j] = vj;
+            }
+            m4[k] = mv;
+            v4[k] = vv;
+            w4[k] = wv;
+        }
+        done = n4 << 2;
     }
+    for (long k = done + i; k < n; k += stride) adam_one(w[k], g[k], m[k], v[k], alpha, omb1, omb2, eps, gs);
 }
 __global__ void momentum_kernel(float *w, const float *g, float *acc, long n, float lr, float mom, float gs) {
     OPT_LOOP(n) {
