@@ -4,8 +4,10 @@ img/s training Darknet-19 YOLOv2 VOC-20 416x416 bf16, batch 16 per GPU (configs[
 over N GPUs of one node (one process per GPU, RCCL gradient all-reduce overlapped with backward).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8                       (re-executes itself under torch.distributed.run: one rank per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 8 --global-batch 64 --names 80     (BASELINE configs[2]: strong scaling, 8 images per GPU)
 
 A "step" = per-image standardisation -> forward (batch-stat BN) -> YOLOv2 loss fwd+bwd -> backward
 -> gradient all-reduce (N>1) -> Adam, on a synthetic batch that is already resident in HBM.
@@ -14,7 +16,10 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                 convolutions with > 64 filters) -- algorithmic FLOPs / HIP-event time of its
                 launches inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
   cpu_baseline  the NumPy oracle's training step (oracle/yolo2_ref.py, a port: TF-1.0 cannot run
-                here) on one 416x416 image on the host cores (rank 0, N=1 only)
+                here) on one 416x416 image on the host cores (rank 0, N=1 only), plus SURVEY 8(d)'s other legs: the
+                torch-CPU (oneDNN) conv stack at batch 8 and the single-thread C restatement of the reference NMS
+  detect        BASELINE configs[4]: batch-256 detect p50/p99 with (a) the network's own scores, (b) the sparse and
+                (c) the dense NMS stress inputs of BASELINE.md section 2 written over the decoded boxes
 """
 import argparse
 import json
@@ -121,10 +126,64 @@ def cpu_baseline(names, size, budget_s=30.0):
         R.train_step(spec, params, {}, x, labels, names, anchors, hp, 1e-6, 0)
         t_total += time.time() - t0
         n += 1
-    return {'value': n / t_total, 'unit': 'img/s', 'cores': int(threads), 'kind': 'port',
-            'sample': '%d single-image 416x416 Darknet-19 training steps (fwd+loss+bwd+Adam) of oracle/yolo2_ref.py, NumPy/BLAS f32, %.1f s; '
-                      'CPU restatement of reference semantics (TensorFlow 1.0 unavailable)' % (n, t_total),
-            'host_cores': os.cpu_count()}
+    out = {'value': n / t_total, 'unit': 'img/s', 'cores': int(threads), 'kind': 'port',
+           'sample': '%d single-image 416x416 Darknet-19 training steps (fwd+loss+bwd+Adam) of oracle/yolo2_ref.py, NumPy/BLAS f32, %.1f s; '
+                     'CPU restatement of reference semantics (TensorFlow 1.0 unavailable)' % (n, t_total),
+           'host_cores': os.cpu_count()}
+    # conv stack on torch-CPU (oneDNN, NHWC f32) at the reference's default batch 8 (train.py:156)
+    try:
+        from oracle import torch_cpu_ref as T
+        r = T.time_conv_stack(classes=names, size=size, batch=8, budget_s=12.0)
+        out['torch_cpu_conv_stack'] = {'fwd_img_s': r['fwd_img_s'], 'train_img_s': r['train_img_s'], 'batch': 8, 'threads': r['threads'],
+                                       'sample': '%d forward / %d forward+backward passes, Darknet-19 %dx%d f32 channels_last' % (r['fwd_iters'], r['train_iters'], size, size)}
+    except Exception as exc:       # a baseline leg must never take the GPU numbers down with it
+        out['torch_cpu_conv_stack'] = {'error': repr(exc)}
+    # the reference's NMS algorithm (utils/postprocess.py:39-51), single thread like the reference, C restatement
+    try:
+        out['nms_ms_per_image'] = cpu_nms_baseline(names)
+    except Exception as exc:
+        out['nms_ms_per_image'] = {'error': repr(exc)}
+    return out
+
+
+def nms_stress_inputs(kind, batch, classes, seed0=0):
+    """The NMS stress inputs of BASELINE.md section 2 (tests/golden/make_golden.py recipes), one seed per image:
+    'sparse': background conf U(0, 0.05), 12 boxes at 0.5-0.9, wh U(0.5, 5.5); 'dense': conf U(0, 0.5), wh U(0, 4) -- the
+    reference's worst case (69.5 s per image in its Python loop).  Returns conf [B,845,C], xy_min, xy_max [B,845,2] (f32)."""
+    conf = np.zeros((batch, 845, classes), np.float32)
+    mn = np.zeros((batch, 845, 2), np.float32)
+    mx = np.zeros((batch, 845, 2), np.float32)
+    for i in range(batch):
+        rng = np.random.RandomState(seed0 + i)
+        if kind == 'sparse':
+            c = rng.uniform(0, 0.05, (845, classes)).astype(np.float32)
+            hot = rng.choice(845, 12, replace=False)
+            c[hot, rng.randint(0, classes, 12)] = rng.uniform(0.5, 0.9, 12).astype(np.float32)
+            cen, wh = rng.uniform(0, 13, (845, 2)), rng.uniform(0.5, 5.5, (845, 2))
+        else:
+            c = rng.uniform(0, 0.5, (845, classes)).astype(np.float32)
+            cen, wh = rng.uniform(0, 13, (845, 2)), rng.uniform(0, 4, (845, 2))
+        conf[i] = c
+        mn[i] = (cen - wh / 2).astype(np.float32)
+        mx[i] = (cen + wh / 2).astype(np.float32)
+    return conf, mn, mx
+
+
+def cpu_nms_baseline(classes):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libnms_ref.so'))
+    P = ctypes.POINTER(ctypes.c_float)
+    res = {'threads': 1, 'impl': 'oracle/nms_ref.c (C restatement of utils/postprocess.py:39-51; the reference itself is a Python loop: '
+                                 '0.245 s sparse / 69.5 s dense per image, BASELINE.md)'}
+    for kind, n_img in (('sparse', 8), ('dense', 4)):
+        conf, mn, mx = nms_stress_inputs(kind, n_img, classes)
+        order = np.zeros(845, np.int64)
+        t0 = time.time()
+        for i in range(n_img):
+            lib.nms_ref(conf[i].ctypes.data_as(P), mn[i].ctypes.data_as(P), mx[i].ctypes.data_as(P), ctypes.c_long(845), ctypes.c_long(classes),
+                        ctypes.c_float(0.3), ctypes.c_float(0.4), order.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
+        res[kind] = (time.time() - t0) / n_img * 1e3
+    return res
 
 
 def main():
@@ -133,6 +192,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (weak scaling)')
+    ap.add_argument('--global-batch', type=int, default=0, help='fixed total batch split over the GPUs (strong scaling; BASELINE configs[2] = 64 on 8)')
     ap.add_argument('--names', type=int, default=20, choices=[20, 80])
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
@@ -141,11 +201,29 @@ def main():
     ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run (RCCL over xGMI)
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     from yolo_tf_amd.parallel import init_distributed
     import torch.distributed as dist
     rank, local_rank, world = init_distributed()
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world)
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch %d is not divisible by %d GPUs' % (args.global_batch, world))
+        args.batch = args.global_batch // world
 
     from yolo_tf_amd.session import TrainSession
     from yolo_tf_amd.utils import data
@@ -204,11 +282,14 @@ def main():
         peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MATRIX_PEAK_TFLOPS
         out = {
             'metric': 'train_throughput', 'value': value, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'Darknet-19 YOLOv2 VOC-%d %dx%d training step (standardise+fwd+loss+bwd+Adam), batch %d per GPU (BASELINE configs[1])'
-                                   % (args.names, args.size, args.size, args.batch),
-                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)'},
+            'config': {'workload': 'Darknet-19 YOLOv2 %s-%d %dx%d training step (standardise+fwd+loss+bwd+Adam), batch %d per GPU (%s)'
+                                   % ('VOC' if args.names == 20 else 'COCO', args.names, args.size, args.size, args.batch,
+                                      'BASELINE configs[2]' if (strong and args.names == 80) else 'BASELINE configs[1]' if (args.names == 20 and args.batch == 16) else 'variant'),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)',
+                       'collective': ('RCCL all-reduce (%s), %d ranks, %d buckets' % (dist.get_backend(), dist.get_world_size(), len(sess.reducer.buckets)))
+                       if world > 1 else 'none (1 rank)'},
             'whole_step_tflops': value * gflop / 1e3,
             'whole_step_frac_of_mfma_peak': value * gflop / 1e3 / peak / world,
             'total_loss': loss['total_loss'],
@@ -239,23 +320,70 @@ def main():
 
 
 def detect_latency(args, basedir, batch=256, iters=30):
-    """BASELINE configs[4]: batch-256 416x416 detect (forward + decode + on-GPU NMS), p50/p99 latency."""
+    """BASELINE configs[4]: batch-256 416x416 detect (standardise + forward + decode + on-GPU NMS), p50/p99 latency.
+    Random-init weights give conf ~ 0.5/C << 0.3, so the network's own scores leave the NMS nothing to suppress; the figure
+    that includes real NMS work overwrites the decoded boxes with the stress inputs of BASELINE.md section 2 (sparse
+    realistic and the reference's dense worst case, a different draw per image) between decode and NMS -- a 22 MB
+    device copy that is inside the timed region."""
     from yolo_tf_amd.session import DetectSession
     b, _ = make_builder('darknet', args.names, args.size, False, basedir)
     sess = DetectSession(b, batch, dtype=args.dtype, seed=0)
     images = torch.rand(batch, args.size, args.size, 3, device='cuda') * 255.0
-    for _ in range(3):
-        sess.detect(images, 0.3, 0.4)
-    torch.cuda.synchronize()
-    times = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        sess.detect(images, 0.3, 0.4)
+    cells = (args.size // 32) ** 2 * len(b.anchors)
+
+    def pct(times):
+        times = sorted(times)
+        return times[len(times) // 2], times[min(len(times) - 1, int(len(times) * 0.99))]
+
+    def run(stress):
+        sess.run(images, 0, check_numerics=False)
+        if stress is not None:
+            sess.conf.copy_(stress[0])
+            sess.xy_min.copy_(stress[1])
+            sess.xy_max.copy_(stress[2])
+        sess.nms(0.3, 0.4)
+
+    out = {'batch': batch, 'iters': iters}
+    modes = [('network_scores', None)]
+    if cells == 845:
+        for kind in ('sparse', 'dense'):
+            modes.append((kind, [torch.from_numpy(a).cuda() for a in nms_stress_inputs(kind, batch, args.names, seed0=1000)]))
+    for name, stress in modes:
+        for _ in range(3):
+            run(stress)
         torch.cuda.synchronize()
-        times.append((time.perf_counter() - t0) * 1e3)
-    times.sort()
-    return {'batch': batch, 'p50_ms': times[len(times) // 2], 'p99_ms': times[min(len(times) - 1, int(len(times) * 0.99))],
-            'img_per_s': batch / (times[len(times) // 2] * 1e-3), 'iters': iters}
+        times = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            run(stress)
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+        p50, p99 = pct(times)
+        entry = {'p50_ms': p50, 'p99_ms': p99, 'img_per_s': batch / (p50 * 1e-3)}
+        if stress is not None:
+            # the NMS launch alone on the same inputs (HIP events around it; the scores are restored before every launch)
+            ev = []
+            for _ in range(10):
+                sess.conf.copy_(stress[0])
+                a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                sess.nms(0.3, 0.4)
+                z.record()
+                ev.append((a, z))
+            torch.cuda.synchronize()
+            nms_ms = sorted(x.elapsed_time(y) for x, y in ev)[len(ev) // 2]
+            kept = int((sess.conf.max(dim=2).values > 0.3).sum().item())
+            nbytes = batch * cells * (2 * args.names + 4) * 4          # scores in + out, corners in (SURVEY 8d: 845*(C+4)*4 B in per image)
+            entry.update({'nms_only_ms': nms_ms, 'nms_us_per_image': nms_ms * 1e3 / batch, 'boxes_kept_per_image': kept / batch,
+                          'nms_algorithmic_GBps': nbytes / (nms_ms * 1e-3) / 1e9,
+                          'nms_bound': 'latency / LDS (O(C*N^2) IoU tests on an 81 KB per-image payload): HBM roofline fraction %.4f'
+                                       % (nbytes / (nms_ms * 1e-3) / 8e12)})
+        out[name] = entry
+    # the headline detect latency is the one that contains NMS work: the dense worst case when available
+    head = out.get('dense', out['network_scores'])
+    out.update({'p50_ms': head['p50_ms'], 'p99_ms': head['p99_ms'], 'img_per_s': head['img_per_s'],
+                'headline': 'dense NMS stress input (every box a candidate)' if 'dense' in out else 'network scores'})
+    return out
 
 
 if __name__ == '__main__':

@@ -7,9 +7,13 @@
  *
  * Conventions
  *   - plain pointers are DEVICE pointers unless marked host; the caller owns every buffer
- *     (outputs and workspaces included); nothing is allocated or freed behind the ABI.
+ *     (outputs and workspaces included); the only allocation behind the ABI is the 32 KiB flag pool named below.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
- *     stream), re-entrant, and keeps no global state besides a thread-local error string.
+ *     stream) and may be issued from several host threads at once.  Library-owned state, all of it: a thread-local
+ *     error string; a thread-local record of the last conv / wgrad plan (diagnostics below); one 32 KiB per-device pool
+ *     of stream-K hand-off flags, created on first use and handed out under a mutex (yolo2_conv2d_ws & co.; freed by
+ *     yolo2_shutdown()); tuning knobs read once from the environment (YOLO2_* A/B switches); and the
+ *     process-wide test switch yolo2_debug_set_wgrad_variant.
  *   - return value: 0 = OK, otherwise a YOLO2_E_* code; yolo2_last_error() describes it.
  *   - activations are NHWC with an explicit pixel stride `ld*` (elements between consecutive
  *     pixels, >= channel count, multiple of 8); lanes in [C, ld) are padding the kernels never
@@ -39,6 +43,21 @@ enum {
 
 int yolo2_abi_version(void);
 const char *yolo2_last_error(void);
+/* releases the library-owned stream-K flag pools (after synchronising their devices); any later call re-creates them */
+int yolo2_shutdown(void);
+
+/* ---- workspace sizes, in bytes, of every entry that takes caller-owned scratch (`ws`): pure host queries ----------------
+ * yolo2_conv2d_workspace_bytes: the largest scratch any variant of yolo2_conv2d_ws / _bn / _bias_leaky can use for the
+ * shape (stream-K: one f32 256x128 tile slot per CU = 33.5 MB on MI355X; K-sliced grids: the f32 [B*H*W][Nf] partial image);
+ * a smaller buffer only disables variants.  The others are exact minimum sizes. */
+size_t yolo2_conv2d_workspace_bytes(int B, int H, int W, int Cp, int Nf, int ksize, int dtype);
+size_t yolo2_bn_workspace_bytes(int C);              /* yolo2_bn_stats*, yolo2_bn_leaky(_pool)_bwd_reduce */
+size_t yolo2_bias_grad_workspace_bytes(int ld);
+size_t yolo2_image_prep_workspace_bytes(int B);
+size_t yolo2_loss_workspace_bytes(int B, int cells, int A);
+size_t yolo2_nms_workspace_bytes(int B, int N, int C);
+size_t yolo2_clip_workspace_bytes(int nseg);
+size_t yolo2_augment_workspace_bytes(int B);
 
 /* ---- convolution: slim.layers.conv2d, model/yolo2/inference.py:37-48,73-118 ------------------
  * Implicit-GEMM NHWC convolution, stride 1, SAME zero padding, ksize 1 or 3:
@@ -203,6 +222,13 @@ int yolo2_head_decode(const void *logits, int ld, const float *anchors, float *c
                       float *xy_min, float *xy_max, int *nan_flag, int B, int cell_h, int cell_w,
                       int A, int C, int dtype, void *stream);
 
+/* The other Model attributes the reference's callers read (demo_detect.py:62: prob, iou, xy_min, wh; model/yolo2/__init__.py:36-56),
+ * f32: iou [B,cells,A] = sigmoid(ch 0), prob [B,cells,A,C] = softmax(classes), xy [B,cells,A,2] = cell_xy + sigmoid(ch 1:3),
+ * wh [B,cells,A,2] = exp(ch 3:5) * anchors.  Any output may be NULL (at least one must not be). */
+int yolo2_head_decode_attrs(const void *logits, int ld, const float *anchors, float *iou, float *prob,
+                            float *xy, float *wh, int B, int cell_h, int cell_w, int A, int C,
+                            int dtype, void *stream);
+
 /* ---- loss forward+backward: Objectives, model/yolo2/__init__.py:62-94 + Builder :114-119 -----
  * labels (f32): mask[B,cells], prob[B,cells,C], coords[B,cells,4], off_min/off_max[B,cells,2],
  * areas[B,cells].  hparam = HOST pointer to the 4 weights {iou_best, iou_normal, coords, prob}.
@@ -234,6 +260,20 @@ int yolo2_adagrad(float *w, const float *g, float *acc, long n, float lr, float 
                   void *stream);
 int yolo2_adadelta(float *w, const float *g, float *acc, float *acc_update, long n, float lr,
                    float rho, float eps, float gscale, void *stream);
+/* tf.train.FtrlOptimizer (train.py:78, config.ini [optimizer_ftrl]): TF-1.0 ApplyFtrl;
+ * accum starts at initial_accumulator_value, linear at 0; lr_power <= 0 (-0.5 takes the sqrt form) */
+int yolo2_ftrl(float *w, const float *g, float *accum, float *linear, long n, float lr, float lr_power,
+               float l1, float l2, float gscale, void *stream);
+/* x *= scale (1/world averaging of the all-reduced gradient ahead of clip_by_norm) */
+int yolo2_scale(float *x, long n, float scale, void *stream);
+/* x[a:b] = 0 for nranges half-open element ranges given as a HOST array {a0,b0,a1,b1,...}: the accumulating filter
+ * gradients (yolo2_conv2d_wgrad_accumulates) are cleared per step, nothing else */
+int yolo2_zero_ranges(float *x, const long *ranges_host, int nranges, void *stream);
+/* Inference-time batch-norm folding for yolo2_conv2d_bias_leaky (slim.batch_norm is_training=False,
+ * model/yolo2/inference.py:62-66): Wf[r,n] = W[r,n]*s[n], bias[n] = beta[n] - moving_mean[n]*s[n],
+ * s = gamma/sqrt(moving_var+eps); W, Wf: HWIO f32 viewed as [rows = k*k*Cin][C]. */
+int yolo2_bn_fold(const float *W, const float *gamma, const float *beta, const float *moving_mean,
+                  const float *moving_var, float *Wf, float *bias, long rows, int C, float eps, void *stream);
 /* per-tensor tf.clip_by_norm (slim create_train_op clip_gradient_norm, train.py:127-129):
  * seg_off int64[nseg+1] element offsets into g; ws >= nseg doubles */
 int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, double *ws,
@@ -242,18 +282,16 @@ int yolo2_clip_by_norm(float *g, const long *seg_off, int nseg, float clip, doub
 /* ---- diagnostics -----------------------------------------------------------------------------
  * fills out[64*4] with the raw result of ds_read_b64_tr_b16 over a 0..N ramp (layout self-test) */
 int yolo2_selftest_tr16(short *out, void *stream);
-
-/* Whole backward of the image layer -- conv(3 channels in an 8-wide pixel, 32 filters, no dX needed) -> batch norm -> leaky
- * -> 2x2/2 max pool (model/yolo2/inference.py:73-74 under tf.gradients) -- in ONE pass over (X, Y, dP, idx): equals
- * yolo2_bn_leaky_pool_bwd_reduce + _apply + yolo2_conv2d_wgrad, but dY (177 MB at batch 16) is never formed: the filter
- * gradient is evaluated in closed form from sum xs*g, sum xs*y, sum xs and the two BN sums (derivation in
- * csrc/conv_first.hip).  X [B,H,W,8], Y [B,H,W,32] (raw conv output), dP [B,H/2,W/2,32], idx from yolo2_bn_leaky_pool;
- * dW [3,3,Cin,32] f32 is OVERWRITTEN.  scratch: >= YOLO2_IMAGE_LAYER_BWD_SCRATCH floats, all zero on entry, left zero.
- * bf16 only. */
-#define YOLO2_IMAGE_LAYER_BWD_SCRATCH 8192
-int yolo2_image_layer_bwd(const void *X, const void *Y, const void *dP, const unsigned char *idx, const float *mean, const float *var,
-                          const float *gamma, const float *beta, float *dgamma, float *dbeta, float *dW, float *scratch, int B,
-                          int H, int W, int Cin, float eps, float alpha, int dtype, void *stream);
+/* Which kernel variant the calling thread's most recent yolo2_conv2d* / yolo2_conv2d_wgrad call launched (the choice is
+ * shape-driven, so parity tests assert that the variant they mean to check is the one that ran):
+ *   conv plan  out8 = {tile pixels BM, tile filters BN, waves, 16-byte chunks per K row, LDS stages,
+ *                      split (0 none, 1 K-sliced + finishing kernel, 2 stream-K), grid x, grid y};  all -1 = first-layer kernel
+ *   wgrad plan out8 = {tile channels BC, tile filters BN, waves, taps paired, pixel ranges, XCD-local placement,
+ *                      workgroups, direct store (no atomics)};                                      all -1 = first-layer kernel */
+int yolo2_debug_last_conv_plan(int *out8);
+int yolo2_debug_last_wgrad_plan(int *out8);
+/* 0 = transpose-read fragment gather (product), 1 = scalar reference gather (layout-proof, slow); process-wide, tests only */
+void yolo2_debug_set_wgrad_variant(int variant);
 
 /* ---- on-device input pipeline: utils/data/__init__.py:50-109,162-175 + utils/preprocess.py:28-71 after JPEG
  * decode.  `src` holds the decoded uint8 RGB images back to back (any sizes); per image the caller supplies the

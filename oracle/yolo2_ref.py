@@ -551,6 +551,24 @@ def adadelta_step(w, g, acc, acc_update, lr, rho=0.95, eps=1e-8):
     return w - ty(lr) * upd, acc, acc_update
 
 
+def ftrl_step(w, g, accum, linear, lr, lr_power=-0.5, l1=0.0, l2=0.0):
+    """[TF-sem] tf.train.FtrlOptimizer (train.py:78; config.ini:55-59) -- ApplyFtrl kernel of TF 1.0:
+    new_accum = accum + g^2; linear += g - (new_accum^-p - accum^-p)/lr * w (sqrt for p = -0.5);
+    w = (l1*sign(linear) - linear) / (new_accum^-p/lr + 2*l2) where |linear| > l1, else 0; accum = new_accum.
+    Slots: accum starts at initial_accumulator_value (0.1), linear at 0."""
+    ty = w.dtype.type
+    new_accum = accum + g * g
+    if lr_power == -0.5:
+        pa, pna = np.sqrt(accum), np.sqrt(new_accum)
+    else:
+        pa, pna = np.power(accum, ty(-lr_power)), np.power(new_accum, ty(-lr_power))
+    linear = linear + (g - (pna - pa) / ty(lr) * w)
+    x = ty(l1) * np.sign(linear) - linear
+    y = pna / ty(lr) + ty(2) * ty(l2)
+    w = np.where(np.abs(linear) > ty(l1), x / y, ty(0)).astype(w.dtype)
+    return w, new_accum, linear
+
+
 def clip_by_norm(g, clip):
     """[TF-sem] slim create_train_op clip_gradient_norm -> per-tensor tf.clip_by_norm."""
     n = np.sqrt((g.astype(np.float64) ** 2).sum())

@@ -27,9 +27,23 @@ def test_library_exports_every_declared_symbol():
 
 def test_binding_table_matches_header():
     from yolo_tf_amd import _lib
-    declared = set(_declared()) - {'yolo2_abi_version', 'yolo2_last_error', 'yolo2_conv2d_wgrad_accumulates'}   # queries, bound separately
-    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    declared = set(_declared())
+    bound = set(_lib.SIGNATURES) | set(_lib.QUERIES)          # status-returning entries | host queries and diagnostics
+    assert declared == bound, declared ^ bound
+    assert not set(_lib.SIGNATURES) & set(_lib.QUERIES)
     _lib.load()
+
+
+def test_workspace_queries_are_host_only_and_match_the_documented_sizes():
+    from yolo_tf_amd import _lib
+    q = _lib.query
+    assert q('yolo2_bn_workspace_bytes', 1024) == 1025 * 1024 * 8
+    assert q('yolo2_bias_grad_workspace_bytes', 432) == 512 * 432 * 8
+    assert q('yolo2_image_prep_workspace_bytes', 16) == 2 * 16 * 8
+    assert q('yolo2_nms_workspace_bytes', 256, 845, 20) == 256 * 845 * 20 * 4
+    assert q('yolo2_loss_workspace_bytes', 16, 169, 5) == (4 * ((16 * 169 * 8 + 255) // 256) + 4) * 4
+    assert q('yolo2_clip_workspace_bytes', 66) == 66 * 8 and q('yolo2_augment_workspace_bytes', 16) == 3 * 16 * 8
+    assert q('yolo2_shutdown') == 0                      # nothing allocated yet: a no-op
 
 
 def test_argument_errors_raise_without_touching_the_gpu():

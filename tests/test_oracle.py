@@ -326,3 +326,37 @@ def test_adam_matches_torch_formula_except_epsilon_placement():
     alpha = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
     np.testing.assert_allclose(w1, w - alpha * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8), rtol=1e-12)
     assert R.exponential_decay(1.0, 250000, 100000, 0.96, True) == 0.96 ** 2
+
+
+def test_torch_cpu_baseline_leg_matches_numpy_oracle():
+    """oracle/torch_cpu_ref.py (bench.py's torch-CPU conv-stack baseline leg) evaluates the same network as the NumPy
+    restatement: same logits on the same weights (training-mode BN), both model families' ops incl. the stride-1 pool."""
+    from oracle import torch_cpu_ref as T
+    for name in ('darknet', 'tiny'):
+        spec = R.SPECS[name](3, 2)
+        params = R.init_params(spec, seed=5, tiny=name == 'tiny')
+        rng = np.random.RandomState(0)
+        x = rng.randn(2, 64, 64, 3).astype(np.float32)
+        net, _ = R.network_forward(spec, params, x, training=True)
+        got = T.forward(T.build(spec, params), torch.from_numpy(x)).detach().numpy()
+        assert np.abs(got - net).max() <= 2e-4 * np.abs(net).max(), name
+
+
+def test_ftrl_known_answer_and_l1_zeroing():
+    """TF-1.0 ApplyFtrl on a hand-computed scalar (see the arithmetic in the comments) and the |linear| <= l1 -> 0 rule."""
+    w, acc, lin = np.float64([1.0]), np.float64([0.1]), np.float64([0.0])
+    g = np.float64([2.0])
+    # new_accum = 4.1; linear = 2 - (sqrt(4.1) - sqrt(0.1)) / 0.5 * 1; x = 0.5 * sign(linear) - linear; y = sqrt(4.1) / 0.5 + 2 * 0.25
+    lin_ref = 2.0 - (np.sqrt(4.1) - np.sqrt(0.1)) / 0.5
+    w_ref = (0.5 * np.sign(lin_ref) - lin_ref) / (np.sqrt(4.1) / 0.5 + 0.5)
+    w1, a1, l1 = R.ftrl_step(w, g, acc, lin, 0.5, -0.5, 0.5, 0.25)
+    assert abs(w1[0] - w_ref) < 1e-12 and abs(a1[0] - 4.1) < 1e-12 and abs(l1[0] - lin_ref) < 1e-12
+    assert abs(w_ref - 0.2016042) < 1e-6
+    w2, _, _ = R.ftrl_step(w, g, acc, lin, 0.5, -0.5, 5.0, 0.0)       # |linear| = 1.417 <= l1 = 5 -> exactly zero
+    assert w2[0] == 0.0
+    # general power agrees with the sqrt form at p = -0.5 (two code paths of the kernel)
+    rng = np.random.RandomState(0)
+    w, g = rng.randn(100), rng.randn(100)
+    a = R.ftrl_step(w, g, np.full(100, 0.1), np.zeros(100), 0.1, -0.5, 0.01, 0.02)
+    b = R.ftrl_step(w, g, np.full(100, 0.1), np.zeros(100), 0.1, -0.5000000001, 0.01, 0.02)
+    assert np.allclose(a[0], b[0], rtol=1e-7, atol=1e-9)

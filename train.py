@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from yolo_tf_amd import checkpoint, utils
-from yolo_tf_amd.parallel import init_distributed
+from yolo_tf_amd.parallel import agree, init_distributed, sync_replicas
 from yolo_tf_amd.session import TrainSession
 from yolo_tf_amd.utils import data as udata
 
@@ -111,6 +111,8 @@ def main():
     if args.delete and rank == 0:
         logging.warning('delete logging directory: ' + logdir)
         shutil.rmtree(logdir, ignore_errors=True)
+    if world > 1:
+        torch.distributed.barrier()          # nobody looks for checkpoints while rank 0 is still deleting them
     utils.ensure_names(config)
     width = config.getint(model, 'width')
     height = config.getint(model, 'height')
@@ -126,14 +128,17 @@ def main():
                            gradient_clip=args.gradient_clip, config=config, seed=seed, world_size=world,
                            bucket_mb=config.getfloat('mi355x', 'bucket_mb') if config.has_option('mi355x', 'bucket_mb') else 64.0)
     logging.warning('optimizer=%s, dtype=%s, world=%d, parameters=%d' % (args.optimizer, dtype, world, session.engine.n_params))
-    latest = checkpoint.latest_checkpoint(logdir)
+    # rank 0 alone chooses and reads the checkpoint; the others receive parameters, statistics, optimizer slots and
+    # global_step from it (same seed -> same initial weights anyway, but a restore must not depend on what each rank sees)
+    latest = checkpoint.latest_checkpoint(logdir) if rank == 0 else None
     if latest:
         step = checkpoint.restore(latest, session)
         logging.warning('resuming from %s (global_step=%d)' % (latest, step))
-    elif args.transfer:
+    elif args.transfer and rank == 0:
         path = os.path.expanduser(os.path.expandvars(args.transfer))
         logging.warning('transferring from ' + path)
         checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+    sync_replicas(session)
     logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
     if args.data == 'synthetic':
         data = SyntheticData(args.batch_size, len(builder.names), width, height, cell_width, cell_height, seed * world + rank + 1)
@@ -152,25 +157,42 @@ def main():
         data = NpzData(args.data, args.batch_size, seed, rank, world)
     last_summary = last_save = t_rate = time.time()
     n_rate = 0
+    sync_every = 1 if world == 1 else 20     # data parallel: decisions only one rank can make are agreed on every 20 steps
+    device = session.engine.device
     while args.steps is None or session.global_step < args.steps:
         images, labels = data.next()
         session.step(images, labels)
         n_rate += 1
+        last = args.steps is not None and session.global_step >= args.steps
+        if not (last or session.global_step % sync_every == 0):
+            continue
         now = time.time()
-        if now - last_summary >= args.summary_secs or (args.steps is not None and session.global_step >= args.steps):
+        # every rank takes the same branches: rank 0's clock decides, any rank's non-finite loss stops all of them
+        # (a rank that raised alone would leave the others waiting in the next all-reduce)
+        want_summary = rank == 0 and (now - last_summary >= args.summary_secs or last)
+        want_save = rank == 0 and now - last_save >= args.save_secs
+        want_summary, want_save = agree([want_summary, want_save], device)
+        if want_summary:
             s = session.fetch()
+            if hasattr(data, 'pipe'):
+                data.pipe.check()        # objects outside the grid / bad class ids / negative extents: the reference raises there
             rate = n_rate * args.batch_size * world / (time.time() - t_rate)
             if rank == 0:
                 logging.warning('step %d: total_loss=%.6f iou_best=%.6f iou_normal=%.6f coords=%.6f prob=%.6f (%.1f img/s)'
                                 % (session.global_step, s['total_loss'], s['iou_best'], s['iou_normal'], s['coords'], s['prob'], rate))
-            if not np.isfinite(s['total_loss']):
-                raise FloatingPointError('total_loss is not finite')
+            (bad,) = agree([not np.isfinite(s['total_loss'])], device)
+            if bad:
+                raise FloatingPointError('total_loss is not finite (on at least one rank)')
             last_summary, t_rate, n_rate = now, time.time(), 0
-        if rank == 0 and now - last_save >= args.save_secs:
-            logging.warning('saved ' + checkpoint.save(logdir, session))
+        if want_save:
+            if rank == 0:
+                logging.warning('saved ' + checkpoint.save(logdir, session))
             last_save = now
     if rank == 0:
         logging.warning('saved ' + checkpoint.save(logdir, session))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -36,7 +36,6 @@ SIGNATURES = {
     'yolo2_bn_leaky_pool': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
-    'yolo2_image_layer_bwd': [_p] * 12 + [_i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_augment_images': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
     'yolo2_transform_labels': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p],
     'yolo2_bn_stats': [_p, _p, _p, _p, _l, _i, _i, _p],
@@ -54,6 +53,7 @@ SIGNATURES = {
     'yolo2_bias_grad': [_p, _i, _p, _p, _l, _i, _i, _p],
     'yolo2_image_prep': [_p, _p, _p, _i, _i, _i, _i, _p],
     'yolo2_head_decode': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_head_decode_attrs': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_nms': [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     'yolo2_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
@@ -63,8 +63,32 @@ SIGNATURES = {
     'yolo2_adagrad': [_p, _p, _p, _l, _f, _f, _p],
     'yolo2_adadelta': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _p],
     'yolo2_clip_by_norm': [_p, _p, _i, _f, _p, _p],
+    'yolo2_ftrl': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
+    'yolo2_scale': [_p, _l, _f, _p],
+    'yolo2_zero_ranges': [_p, _p, _i, _p],
+    'yolo2_bn_fold': [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _p],
     'yolo2_selftest_tr16': [_p, _p],
 }
+
+# host queries / diagnostics: (restype, argtypes); bound in load() next to the status-returning entries above
+QUERIES = {
+    'yolo2_abi_version': (_i, []),
+    'yolo2_last_error': (ctypes.c_char_p, []),
+    'yolo2_shutdown': (_i, []),
+    'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
+    'yolo2_debug_set_wgrad_variant': (None, [_i]),
+    'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
+    'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
+    'yolo2_conv2d_workspace_bytes': (ctypes.c_size_t, [_i] * 7),
+    'yolo2_bn_workspace_bytes': (ctypes.c_size_t, [_i]),
+    'yolo2_bias_grad_workspace_bytes': (ctypes.c_size_t, [_i]),
+    'yolo2_image_prep_workspace_bytes': (ctypes.c_size_t, [_i]),
+    'yolo2_loss_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i]),
+    'yolo2_nms_workspace_bytes': (ctypes.c_size_t, [_i, _i, _i]),
+    'yolo2_clip_workspace_bytes': (ctypes.c_size_t, [_i]),
+    'yolo2_augment_workspace_bytes': (ctypes.c_size_t, [_i]),
+}
+
 
 class AugmentParams(ctypes.Structure):
     """yolo2_augment_params (include/yolo2_hip.h)."""
@@ -92,20 +116,21 @@ def load():
             'HIP extension %s is missing: run `python yolo_tf_amd/csrc/build.py` (or __graft_entry__.build()). '
             'There is no CPU fallback.' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    lib.yolo2_last_error.restype = ctypes.c_char_p
-    lib.yolo2_last_error.argtypes = []
-    lib.yolo2_abi_version.restype = _i
-    lib.yolo2_abi_version.argtypes = []
-    for name, args in SIGNATURES.items():
+    for name, (res, args) in QUERIES.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
         fn.restype = _i
         fn.argtypes = args
-    lib.yolo2_conv2d_wgrad_accumulates.restype = _i        # a query (0 / 1), not a status
-    lib.yolo2_conv2d_wgrad_accumulates.argtypes = [_i] * 9
-    lib.yolo2_debug_set_wgrad_variant.restype = None
-    lib.yolo2_debug_set_wgrad_variant.argtypes = [_i]
     _lib = lib
     return lib
+
+
+def query(name, *args):
+    """Host-side query of include/yolo2_hip.h (workspace sizes, plans): returns the raw value."""
+    return getattr(load(), name)(*args)
 
 
 def call(name, *args):

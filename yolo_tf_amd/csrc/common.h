@@ -18,9 +18,6 @@ void yolo2_set_error(const char *fmt, ...);
 bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize);
 int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st,
                        const float *bn_shift = nullptr, float *bn_part = nullptr);
-int y2_first_layer_bwd_fused(const void *X, const void *Y, const void *dP, const unsigned char *idx, const float *mean, const float *var,
-                             const float *gamma, const float *beta, float *dgamma, float *dbeta, float *dW, float *scratch, int B, int H, int W,
-                             int Cin, float eps, float alpha, hipStream_t st);
 int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int dtype, hipStream_t st);
 
 // batch-norm partial sums produced by the convolution epilogue: [2][Y2_BN_PART_ROWS][C] f32 (elementwise.hip finalises)

@@ -43,6 +43,7 @@
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
 
 template <typename T> struct Mma;
@@ -412,19 +413,36 @@ static const Tune &tune() {   // tuning knobs (defaults = measured best); env ov
 // launch takes the next set round-robin (launches on different streams may overlap) and leaves it zero (every flag is
 // cleared by the one workgroup that waits for it), so no per-launch memset node is needed (16 of them cost 83 us a step).
 #define Y2_STREAM_FLAG_SETS 8
+// The ONE piece of library-owned device state (declared in include/yolo2_hip.h): 32 KiB per device, created on first use
+// under a mutex, handed out round-robin under the same mutex (host threads may launch concurrently), freed by yolo2_shutdown().
+static std::mutex g_flag_mutex;
+static unsigned *g_flag_pool[64] = {nullptr};
+static unsigned g_flag_counter[64] = {0};
 static unsigned *stream_flags() {
-    static unsigned *pool[64] = {nullptr};
-    static unsigned counter[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!pool[dev]) {
+    std::lock_guard<std::mutex> lock(g_flag_mutex);
+    if (!g_flag_pool[dev]) {
         unsigned *p = nullptr;
         const size_t bytes = (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_WORDS * sizeof(unsigned);
         if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
-        pool[dev] = p;
+        g_flag_pool[dev] = p;
     }
-    return pool[dev] + (size_t)(counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_WORDS;
+    return g_flag_pool[dev] + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_WORDS;
+}
+extern "C" int yolo2_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_flag_mutex);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (int d = 0; d < 64; ++d)
+        if (g_flag_pool[d]) {
+            if (hipSetDevice(d) == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree(g_flag_pool[d]); }
+            g_flag_pool[d] = nullptr;
+            g_flag_counter[d] = 0;
+        }
+    (void)hipSetDevice(cur);
+    return YOLO2_OK;
 }
 
 // number of K slices: when the M x N tile grid alone cannot fill 256 CUs with ~2-3 resident workgroups
@@ -439,9 +457,17 @@ static int choose_ksplit(int tiles, int nk, int target) {
     return ks < 1 ? 1 : ks;
 }
 
+// the plan of the calling thread's most recent launch (yolo2_debug_last_conv_plan): tests assert that the variant they
+// mean to check is the one that ran, since the choice is shape-driven
+static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
-    conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<gridv, NWv * 64, 0, st>>>(           \
-        (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha)
+    do {                                                                                                           \
+        const dim3 g_ = (gridv);                                                                                   \
+        const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
+        for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
+        conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<g_, NWv * 64, 0, st>>>(          \
+            (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha); \
+    } while (0)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
 #define Y2_IGEMM_KS_CT(BNv, WGNv, NSv, SPLITv, NWv, gridv)                              \
@@ -567,6 +593,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     if (first_direct && !bias && act_alpha == 1.0f && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
+        for (int i = 0; i < 8; ++i) g_last_plan[i] = -1;      // direct first-layer kernel (conv_first.hip)
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
@@ -577,6 +604,26 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     Y2_CHECK_LAUNCH();
     if (bn_part && !stats_done)       // K-sliced path: statistics from a pass over the finished output
         return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream);
+    return YOLO2_OK;
+}
+
+extern "C" size_t yolo2_conv2d_workspace_bytes(int B, int H, int W, int Cp, int Nf, int ksize, int dtype) {
+    // the largest scratch any variant of yolo2_conv2d_ws / _bn / _bias_leaky can use for this shape: one f32 256x128 tile slot
+    // per CU (stream-K) or the f32 [M][Nf] partial-sum image (K-sliced grids); smaller buffers only disable variants
+    if (!(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0) || !(dtype == YOLO2_F32 || dtype == YOLO2_BF16)) return 0;
+    const Tune &tu = tune();
+    const size_t M = (size_t)B * H * W;
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    size_t need = (size_t)tu.cus * 256 * 128 * sizeof(float);
+    const long tiles = (long)cdiv((long)M, 128) * cdiv(Nf, 128);
+    if (choose_ksplit((int)(tiles > (1 << 30) ? (1 << 30) : tiles), ksize * ksize * cdiv(Cp, 4 * vec), tu.target_blocks) > 1 && M * Nf * sizeof(float) > need)
+        need = M * Nf * sizeof(float);
+    return need;
+}
+
+extern "C" int yolo2_debug_last_conv_plan(int *out8) {
+    if (!out8) return YOLO2_E_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = g_last_plan[i];
     return YOLO2_OK;
 }
 

@@ -29,6 +29,7 @@
 // layers, two taps per 64-row tile for <= 32 input channels (PAIR).  The per-DMA-piece border bookkeeping ((h, w) of every
 // staged pixel row, advanced branch-free by a constant pixel step) is the kernel's main non-MFMA cost.
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -292,8 +293,15 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     else write_tile(std::true_type{});
 }
 
-static int g_wgrad_variant = 0;
+static std::atomic<int> g_wgrad_variant{0};      // tests only (scalar reference gather); process-wide by design
 extern "C" void yolo2_debug_set_wgrad_variant(int v) { g_wgrad_variant = v; }
+// plan of the calling thread's most recent launch: {BC, BNN, waves, PAIR, pixel ranges, XCD remap, blocks, direct store}
+static thread_local int g_last_wgrad_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int yolo2_debug_last_wgrad_plan(int *out8) {
+    if (!out8) return YOLO2_E_ARG;
+    for (int i = 0; i < 8; ++i) out8[i] = g_last_wgrad_plan[i];
+    return YOLO2_OK;
+}
 
 struct WgradPlan { int tiles, ks, remap, mchunk, blocks; };
 // Pixel-range split (every block ends with one f32 atomic per output element, so fewer, longer blocks =
@@ -353,6 +361,11 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     dim3 grid(pl.blocks);
     const unsigned x_bytes = (unsigned)((size_t)M * ldx * sizeof(T)), y_bytes = (unsigned)((size_t)M * ldy * sizeof(T));
     static const int nw8 = getenv("YOLO2_WGRAD_NW8") ? atoi(getenv("YOLO2_WGRAD_NW8")) : 1;
+    {
+        const bool w8 = BC >= 128 && g_wgrad_variant == 0 && nw8, pair = BC == 64 && g_wgrad_variant == 0 && wgrad_pairs_taps(Cin, ksize);
+        const int plan[8] = {BC, BNN, w8 ? 8 : 4, pair ? 1 : 0, pl.ks, remap, pl.blocks, direct};
+        for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = plan[i];
+    }
     if constexpr (BC >= 128) {
         if (g_wgrad_variant == 0 && nw8) {
             conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
@@ -404,6 +417,7 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
     if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize) && (dtype == YOLO2_F32 || dtype == YOLO2_BF16)) {
         y2_first_layer_wgrad(X, dY, dW, B, H, W, Cin, dtype, st);                       // image layer: direct kernel (conv_first.hip)
+        for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = -1;
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }

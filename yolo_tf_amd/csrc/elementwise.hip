@@ -1164,6 +1164,83 @@ __global__ void adadelta_kernel(float *w, const float *g, float *acc, float *acc
         w[i] = w[i] - lr * u;
     }
 }
+// [TF-sem] ApplyFtrl (tf.train.FtrlOptimizer, reference train.py:78): accum starts at initial_accumulator_value, linear at 0.
+//   new_accum = accum + g^2;  linear += g - (new_accum^-p - accum^-p) / lr * w;   (p = learning_rate_power, sqrt when p = -0.5)
+//   w = |linear| > l1 ? (l1 * sign(linear) - linear) / (new_accum^-p / lr + 2 * l2) : 0
+__global__ void ftrl_kernel(float *w, const float *g, float *accum, float *linear, long n, float lr, float lr_power, float l1, float l2, float gs) {
+    const bool half = lr_power == -0.5f;
+    OPT_LOOP(n) {
+        const float gi = g[i] * gs;
+        const float a = accum[i], na = a + gi * gi;
+        const float pa = half ? sqrtf(a) : powf(a, -lr_power), pna = half ? sqrtf(na) : powf(na, -lr_power);
+        const float li = linear[i] + (gi - (pna - pa) / lr * w[i]);
+        const float sgn = li > 0.f ? 1.f : (li < 0.f ? -1.f : 0.f);
+        const float x = l1 * sgn - li;
+        const float y = pna / lr + 2.0f * l2;
+        w[i] = fabsf(li) > l1 ? x / y : 0.f;
+        linear[i] = li;
+        accum[i] = na;
+    }
+}
+__global__ void scale_kernel(float *x, long n, float sc) {
+    OPT_LOOP(n) x[i] = x[i] * sc;
+}
+// inference-time batch-norm folding: Wf[r, n] = W[r, n] * s[n], bias[n] = beta[n] - mean[n] * s[n], s = gamma / sqrt(var + eps)
+__global__ void bn_fold_kernel(const float *__restrict__ W, const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ mean,
+                               const float *__restrict__ var, float *__restrict__ Wf, float *__restrict__ bias, long rows, int C, float eps) {
+    const long total = rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % C);
+        const float sc = gamma[n] / sqrtf(var[n] + eps);
+        Wf[i] = W[i] * sc;
+        if (i < C) bias[n] = beta[n] - mean[n] * sc;
+    }
+}
+
+extern "C" int yolo2_ftrl(float *w, const float *g, float *accum, float *linear, long n, float lr, float lr_power, float l1, float l2, float gscale, void *stream) {
+    Y2_CHECK_ARG(w && g && accum && linear && n > 0 && lr > 0.f && lr_power <= 0.f);
+    ftrl_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(w, g, accum, linear, n, lr, lr_power, l1, l2, gscale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_scale(float *x, long n, float scale, void *stream) {
+    Y2_CHECK_ARG(x && n > 0);
+    scale_kernel<<<ew_grid(n / 4 + 1), 256, 0, (hipStream_t)stream>>>(x, n, scale);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_zero_ranges(float *x, const long *ranges_host, int nranges, void *stream) {
+    Y2_CHECK_ARG(x && (nranges == 0 || ranges_host) && nranges >= 0);
+    for (int i = 0; i < nranges; ++i) {
+        const long a = ranges_host[2 * i], b = ranges_host[2 * i + 1];
+        Y2_CHECK_ARG(a >= 0 && b >= a);
+        if (b > a && hipMemsetAsync(x + a, 0, (size_t)(b - a) * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+            yolo2_set_error("yolo2_zero_ranges: memset failed");
+            return YOLO2_E_LAUNCH;
+        }
+    }
+    return YOLO2_OK;
+}
+extern "C" int yolo2_bn_fold(const float *W, const float *gamma, const float *beta, const float *moving_mean, const float *moving_var, float *Wf,
+                             float *bias, long rows, int C, float eps, void *stream) {
+    Y2_CHECK_ARG(W && gamma && beta && moving_mean && moving_var && Wf && bias && rows > 0 && C > 0);
+    bn_fold_kernel<<<ew_grid(rows * C), 256, 0, (hipStream_t)stream>>>(W, gamma, beta, moving_mean, moving_var, Wf, bias, rows, C, eps);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ---- workspace sizes (bytes) of the entries that take a caller-owned scratch buffer: the single source of truth for callers
+extern "C" size_t yolo2_bn_workspace_bytes(int C) { return (size_t)1025 * (size_t)(C > 0 ? C : 0) * sizeof(double); }
+extern "C" size_t yolo2_bias_grad_workspace_bytes(int ld) { return (size_t)512 * (size_t)(ld > 0 ? ld : 0) * sizeof(double); }
+extern "C" size_t yolo2_image_prep_workspace_bytes(int B) { return (size_t)2 * (size_t)(B > 0 ? B : 0) * sizeof(double); }
+extern "C" size_t yolo2_clip_workspace_bytes(int nseg) { return (size_t)(nseg > 0 ? nseg : 0) * sizeof(double); }
+extern "C" size_t yolo2_augment_workspace_bytes(int B) { return (size_t)3 * (size_t)(B > 0 ? B : 0) * sizeof(double); }
+extern "C" size_t yolo2_nms_workspace_bytes(int B, int N, int C) { return (size_t)(B > 0 ? B : 0) * (size_t)(N > 0 ? N : 0) * (size_t)(C > 0 ? C : 0) * sizeof(int); }
+extern "C" size_t yolo2_loss_workspace_bytes(int B, int cells, int A) {
+    int lpc = 1;
+    while (lpc < A) lpc *= 2;
+    return (size_t)(4 * (((long)B * cells * lpc + 255) / 256) + 4) * sizeof(float);
+}
 
 extern "C" int yolo2_adam(float *w, const float *g, float *m, float *v, long n, float alpha, float beta1, float beta2, float eps, float gscale, void *stream) {
     Y2_CHECK_ARG(w && g && m && v && n > 0);

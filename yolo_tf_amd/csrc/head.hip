@@ -192,3 +192,45 @@ extern "C" int yolo2_head_decode(const void *logits, int ld, const float *anchor
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
+
+// The remaining Model attributes reference callers read (demo_detect.py:62 uses prob, iou, xy_min, wh; model/yolo2/__init__.py:36-56):
+// iou = sigmoid(ch 0), prob = softmax(classes), xy = cell_xy + sigmoid(ch 1:3), wh = exp(ch 3:5) * anchors.  Any output may be NULL.
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attrs_kernel(const T *__restrict__ logits, int ld, const float *__restrict__ anchors, float *__restrict__ iou,
+                                                           float *__restrict__ prob, float *__restrict__ xy, float *__restrict__ wh, int B, int cell_h,
+                                                           int cell_w, int A, int C) {
+    const int cells = cell_h * cell_w;
+    const long total = (long)B * cells * A;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int a = (int)(gid % A);
+    const long cell_id = gid / A;
+    const int cell = (int)(cell_id % cells);
+    const T *lp = logits + cell_id * ld + a * (5 + C);
+    if (iou) iou[gid] = sigmoidf_((float)lp[0]);
+    if (xy) {
+        xy[gid * 2] = (float)(cell % cell_w) + sigmoidf_((float)lp[1]);
+        xy[gid * 2 + 1] = (float)(cell / cell_w) + sigmoidf_((float)lp[2]);
+    }
+    if (wh) {
+        wh[gid * 2] = expf((float)lp[3]) * anchors[2 * a];
+        wh[gid * 2 + 1] = expf((float)lp[4]) * anchors[2 * a + 1];
+    }
+    if (prob) {
+        float mx = -INFINITY;
+        for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)lp[5 + k]);
+        float den = 0.f;
+        for (int k = 0; k < C; ++k) den += expf((float)lp[5 + k] - mx);
+        for (int k = 0; k < C; ++k) prob[gid * C + k] = expf((float)lp[5 + k] - mx) / den;
+    }
+}
+
+extern "C" int yolo2_head_decode_attrs(const void *logits, int ld, const float *anchors, float *iou, float *prob, float *xy, float *wh,
+                                       int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(logits && anchors && (iou || prob || xy || wh));
+    Y2_CHECK_ARG(B > 0 && cell_h > 0 && cell_w > 0 && A > 0 && C > 0 && ld >= A * (5 + C));
+    const long total = (long)B * cell_h * cell_w * A;
+    Y2_DISPATCH_DTYPE(dtype, decode_attrs_kernel<T><<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const T *)logits, ld, anchors, iou, prob, xy, wh, B, cell_h, cell_w, A, C));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}

@@ -171,17 +171,19 @@ class Engine(object):
                     self.fused_pool[x] = op
                     if self.training:
                         self.conv[producers[x]['name']]['pool_idx'] = torch.zeros(B * (x.h // 2) * (x.w // 2) * x.c, dtype=torch.uint8, device=dev)
-        # f32 partial-sum workspace for K-sliced convolutions: only stages whose M x N tile grid is small
-        # ever slice, so size it for those (B*H*W*N <= 8M elements covers 26x26x512 at batch 16)
-        # off by default: correct (tests/test_kernels_gpu.py::test_image_layer_backward_fused) but measured 0.27 ms SLOWER per
-        # step than the three unfused kernels -- 316 VGPRs leave one wave per SIMD for a pass that is mostly per-element VALU work
-        self.fuse_image_bwd = os.environ.get('YOLO2_FUSE_IMAGE_BWD', '0') != '0'
-        self.image_bwd_scratch = torch.zeros(8192, dtype=torch.float32, device=dev)    # YOLO2_IMAGE_LAYER_BWD_SCRATCH, kept zero
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
         self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
-        self.conv_ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device=dev)   # stream-K: flags + one f32 tile slot per CU
-        self.ws = torch.zeros(1026 * max_c + 2 * B + 64, dtype=torch.float64, device=dev)   # reduction partials
+        # scratch sizes come from the library's own queries (include/yolo2_hip.h yolo2_*_workspace_bytes)
+        conv_bytes = 0
+        for op in self.graph.ops:
+            if op['kind'] == 'conv':
+                x = op['x']
+                for cp, nf in ((pad8(op['cin']), op['cout']), (pad8(op['cout']), op['cin'])):       # forward, data gradient
+                    conv_bytes = max(conv_bytes, ops.workspace_bytes('conv2d', B, x.h, x.w, cp, nf, op['ksize'], ops.dtype_code(T)))
+        self.conv_ws = torch.zeros(conv_bytes // 4 + 1024, dtype=torch.float32, device=dev)   # stream-K tile slots / K-sliced partial image
+        ws_bytes = max(ops.workspace_bytes('bn', max_c), ops.workspace_bytes('bias_grad', max_c)) + ops.workspace_bytes('image_prep', B)
+        self.ws = torch.zeros(ws_bytes // 8 + 64, dtype=torch.float64, device=dev)   # reduction partials
         if self.training:
             # dY scratch ring: the filter gradient of layer L runs on a side stream concurrently with the data gradient
             # (and the following layers' backward) on the main stream, so dY(L) must outlive the next layers' writes
@@ -236,9 +238,8 @@ class Engine(object):
         for op in self.graph.ops:
             if op['kind'] == 'conv' and 'fold_w' in self.conv[op['name']]:
                 st = self.conv[op['name']]
-                scale = self.var[op['gamma'].name] / torch.sqrt(self.var[op['moving_variance'].name] + BN_EPS)
-                torch.mul(self.var[op['weights'].name].view(op['ksize'], op['ksize'], op['cin'], op['cout']), scale, out=st['fold_w'].view(op['ksize'], op['ksize'], op['cin'], op['cout']))
-                torch.sub(self.var[op['beta'].name], self.var[op['moving_mean'].name] * scale, out=st['fold_bias'])
+                ops.bn_fold(self.var[op['weights'].name], self.var[op['gamma'].name], self.var[op['beta'].name], self.var[op['moving_mean'].name],
+                            self.var[op['moving_variance'].name], st['fold_w'], st['fold_bias'], op['ksize'] ** 2 * op['cin'], op['cout'], BN_EPS)
         ops.filter_prep_batch(self._fdesc, self._fdesc_n, self._fdesc_blocks, self.dtype)
         self._filters_dirty = False
 
@@ -291,8 +292,8 @@ class Engine(object):
     def zero_grads(self):
         if self._zero_ranges is None:
             self._zero_ranges = self._plan_grad_zeroing()
-        for a, b in self._zero_ranges:
-            self.grads[a:b].zero_()
+        if self._zero_ranges:
+            ops.zero_ranges(self.grads, self._zero_ranges)
 
     # ---------------------------------------------------------------- forward
     def forward(self):
@@ -391,15 +392,6 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     dgam, dbet = self.gvar[op['gamma'].name], self.gvar[op['beta'].name]
                     pool = self.fused_pool.get(out)
-                    if (pool is not None and x in inputs and self.fuse_image_bwd and self.dtype == torch.bfloat16 and k == 3 and cout == 32
-                            and ldx == 8 and self.gact[pool['out']][1] == 32):
-                        # image layer: no dX is needed, so BN/leaky/pool backward AND the filter gradient collapse into one pass
-                        # over (x, y, dP, idx) -- dY is never formed (yolo2_image_layer_bwd)
-                        ops.image_layer_bwd(xb, yb, self.gact[pool['out']][0], st['pool_idx'], st['mean'], st['var'], gamma, beta, dgam, dbet,
-                                            self.gvar[op['weights'].name], self.image_bwd_scratch, B, x.h, x.w, op['cin'], BN_EPS, LEAKY_ALPHA)
-                        if on_layer_done is not None:
-                            on_layer_done(op, None)
-                        continue
                     if pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
                         dpb, lddp = self.gact[pool['out']]
                         ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,

@@ -28,10 +28,36 @@ class Model(object):
         self.anchors = np.asarray(anchors, np.float32).reshape(-1, 2)
         self.training = training
         assert net.c == len(self.anchors) * (5 + classes)
+        self._session = None
 
     @property
     def cells(self):
         return self.cell_height * self.cell_width
+
+    # The attributes the reference's callers read off the TF graph (`conf, xy_min, xy_max` detect.py:69-72; `prob, iou,
+    # xy_min, wh` demo_detect.py:62) are device tensors of the bound DetectSession's LAST run, shaped like the reference's
+    # [B, cells, A, ...]: `conf / xy_min / xy_max` are the decode kernel's outputs themselves, the rest are produced on
+    # first access by yolo2_head_decode_attrs from the same logits.
+    def bind(self, session):
+        self._session = session
+        return self
+
+    def _bound(self):
+        if self._session is None:
+            raise AttributeError('Model attributes hold values only after DetectSession.run(); build a session first')
+        return self._session
+
+    def _view(self, t, last):
+        s = self._bound()
+        return t.view(s.B, self.cells, len(self.anchors), last) if last else t.view(s.B, self.cells, len(self.anchors))
+
+    conf = property(lambda self: self._view(self._bound().conf, self.classes))
+    xy_min = property(lambda self: self._view(self._bound().xy_min, 2))
+    xy_max = property(lambda self: self._view(self._bound().xy_max, 2))
+    iou = property(lambda self: self._view(self._bound().attrs()['iou'], 0))
+    prob = property(lambda self: self._view(self._bound().attrs()['prob'], self.classes))
+    xy = property(lambda self: self._view(self._bound().attrs()['xy'], 2))
+    wh = property(lambda self: self._view(self._bound().attrs()['wh'], 2))
 
 
 class Objectives(dict):

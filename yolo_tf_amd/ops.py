@@ -134,6 +134,11 @@ def head_decode(logits, ld, anchors, conf, xy_min, xy_max, nan_flag, B, ch, cw, 
          dtype_code(logits.dtype), _stream())
 
 
+def head_decode_attrs(logits, ld, anchors, iou, prob, xy, wh, B, ch, cw, A, C):
+    call('yolo2_head_decode_attrs', ptr(logits), ld, ptr(anchors), ptr(iou), ptr(prob), ptr(xy), ptr(wh), B, ch, cw, A, C,
+         dtype_code(logits.dtype), _stream())
+
+
 def loss(logits, ld, anchors, labels, hparam, objectives, dlogits, ws, B, ch, cw, A, C):
     """labels: 6 device f32 tensors (mask, prob, coords, off_min, off_max, areas); hparam: 4 host floats
     in the order iou_best, iou_normal, coords, prob."""
@@ -144,10 +149,7 @@ def loss(logits, ld, anchors, labels, hparam, objectives, dlogits, ws, B, ch, cw
 
 
 def loss_ws_floats(B, cells, A):
-    lpc = 1
-    while lpc < A:
-        lpc *= 2
-    return 4 * ((B * cells * lpc + 255) // 256) + 4
+    return workspace_bytes('loss', B, cells, A) // 4
 
 
 def nms(conf, xy_min, xy_max, order, ws, B, N, C, thr, thr_iou):
@@ -178,6 +180,30 @@ def adadelta(w, g, acc, accu, n, lr, rho, eps, gscale=1.0):
     call('yolo2_adadelta', ptr(w), ptr(g), ptr(acc), ptr(accu), n, lr, rho, eps, gscale, _stream())
 
 
+def ftrl(w, g, accum, linear, n, lr, lr_power, l1, l2, gscale=1.0):
+    call('yolo2_ftrl', ptr(w), ptr(g), ptr(accum), ptr(linear), n, lr, lr_power, l1, l2, gscale, _stream())
+
+
+def scale(x, n, s):
+    call('yolo2_scale', ptr(x), n, s, _stream())
+
+
+def zero_ranges(x, ranges):
+    """x[a:b] = 0 for every (a, b) in ``ranges`` (element offsets; host list)."""
+    flat = (ctypes.c_long * (2 * len(ranges)))(*[int(v) for ab in ranges for v in ab])
+    call('yolo2_zero_ranges', ptr(x), flat, len(ranges), _stream())
+
+
+def bn_fold(W, gamma, beta, mean, var, Wf, bias, rows, C, eps):
+    call('yolo2_bn_fold', ptr(W), ptr(gamma), ptr(beta), ptr(mean), ptr(var), ptr(Wf), ptr(bias), rows, C, eps, _stream())
+
+
+def workspace_bytes(kind, *args):
+    """Caller-owned scratch size of an entry family: 'conv2d', 'bn', 'bias_grad', 'image_prep', 'loss', 'nms', 'clip', 'augment'
+    (include/yolo2_hip.h yolo2_*_workspace_bytes)."""
+    return int(_lib.query('yolo2_%s_workspace_bytes' % kind, *args))
+
+
 def clip_by_norm(g, seg_off, nseg, clip, ws):
     call('yolo2_clip_by_norm', ptr(g), ptr(seg_off), nseg, clip, ptr(ws), _stream())
 
@@ -187,6 +213,23 @@ def selftest_tr16():
     call('yolo2_selftest_tr16', ptr(out), _stream())
     torch.cuda.synchronize()
     return out.cpu().numpy().reshape(64, 4)
+
+
+CONV_PLAN_KEYS = ('BM', 'BN', 'waves', 'chunks', 'stages', 'split', 'grid_x', 'grid_y')
+WGRAD_PLAN_KEYS = ('BC', 'BN', 'waves', 'pair', 'ranges', 'remap', 'blocks', 'direct')
+
+
+def last_conv_plan():
+    """Variant of this thread's most recent conv2d* launch (include/yolo2_hip.h yolo2_debug_last_conv_plan)."""
+    out = (ctypes.c_int * 8)()
+    _lib.load().yolo2_debug_last_conv_plan(out)
+    return dict(zip(CONV_PLAN_KEYS, list(out)))
+
+
+def last_wgrad_plan():
+    out = (ctypes.c_int * 8)()
+    _lib.load().yolo2_debug_last_wgrad_plan(out)
+    return dict(zip(WGRAD_PLAN_KEYS, list(out)))
 
 
 def set_wgrad_variant(v):
@@ -201,8 +244,3 @@ def transform_labels(objects_class, objects_coord, first_object, mask, prob, coo
                      cell_width, cell_height, error_flag):
     call('yolo2_transform_labels', ptr(objects_class), ptr(objects_coord), ptr(first_object), ptr(mask), ptr(prob), ptr(coords),
          ptr(offset_xy_min), ptr(offset_xy_max), ptr(areas), B, classes, cell_width, cell_height, ptr(error_flag), _stream())
-
-
-def image_layer_bwd(X, Y, dP, idx, mean, var, gamma, beta, dgamma, dbeta, dW, scratch, B, H, W, Cin, eps, alpha):
-    call('yolo2_image_layer_bwd', ptr(X), ptr(Y), ptr(dP), ptr(idx), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
-         ptr(dW), ptr(scratch), B, H, W, Cin, eps, alpha, dtype_code(X.dtype), _stream())

@@ -34,6 +34,7 @@ DEFAULTS = {
     'adagrad': {'initial_accumulator_value': 0.1},
     'momentum': {'momentum': 0.9},
     'rmsprop': {'decay': 0.9, 'momentum': 0.0, 'epsilon': 1e-10},
+    'ftrl': {'learning_rate_power': -0.5, 'initial_accumulator_value': 0.1, 'l1_regularization_strength': 0.0, 'l2_regularization_strength': 0.0},
     'gd': {},
 }
 
@@ -41,7 +42,7 @@ DEFAULTS = {
 class Optimizer(object):
     def __init__(self, name, config, n, device):
         if name not in DEFAULTS:
-            raise KeyError('optimizer %r is not available on this path (adam, adadelta, adagrad, momentum, rmsprop, gd)' % name)
+            raise KeyError('optimizer %r is not available on this path (adam, adadelta, adagrad, momentum, rmsprop, ftrl, gd)' % name)
         self.name = name
         self.hp = dict(DEFAULTS[name])
         section = 'optimizer_' + name
@@ -55,6 +56,7 @@ class Optimizer(object):
             'adam': lambda: [z(), z()], 'adadelta': lambda: [z(), z()],
             'adagrad': lambda: [z(self.hp.get('initial_accumulator_value', 0.1))], 'momentum': lambda: [z()],
             'rmsprop': lambda: [z(1.0), z()],          # [TF-sem] RMSProp's `rms` slot starts at ones
+            'ftrl': lambda: [z(self.hp['initial_accumulator_value']), z()],     # accum, linear
             'gd': lambda: [],
         }[name]()
 
@@ -78,5 +80,7 @@ class Optimizer(object):
             ops.rmsprop(params, grads, s[0], s[1], n, lr, hp['decay'], hp['momentum'], hp['epsilon'], gscale)
         elif self.name == 'adagrad':
             ops.adagrad(params, grads, s[0], n, lr, gscale)
+        elif self.name == 'ftrl':
+            ops.ftrl(params, grads, s[0], s[1], n, lr, hp['learning_rate_power'], hp['l1_regularization_strength'], hp['l2_regularization_strength'], gscale)
         elif self.name == 'adadelta':
             ops.adadelta(params, grads, s[0], s[1], n, lr, hp['rho'], hp['epsilon'], gscale)

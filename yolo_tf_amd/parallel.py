@@ -32,6 +32,31 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def sync_replicas(session, src=0, always=False):
+    """Makes every replica identical to rank ``src``: parameters, BN moving statistics, optimizer slots and global_step
+    (one broadcast each over the flat arenas).  Called once after rank 0 has restored / transferred a checkpoint, so ranks
+    can never start from different files (or one of them from a logdir another rank is deleting)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not always):
+        return
+    e = session.engine
+    for t in [e.params, e.state] + list(session.optimizer.slots):
+        dist.broadcast(t, src=src)
+    step = torch.tensor([session.global_step], dtype=torch.int64, device=e.params.device)
+    dist.broadcast(step, src=src)
+    session.global_step = int(step.item())
+    e._filters_dirty = True
+
+
+def agree(flags, device):
+    """Element-wise MAX over ranks of a short list of integer flags (identity at world size 1): lets every rank take the same
+    branch on a decision only one of them can make (a non-finite loss on its shard, rank 0's wall clock)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [int(f) for f in flags]
+    t = torch.tensor([int(f) for f in flags], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.tolist()]
+
+
 def make_buckets(offsets_sizes, total, bucket_elems):
     """Splits [0, total) at variable boundaries into contiguous buckets of >= bucket_elems elements
     (the last one takes the remainder).  ``offsets_sizes``: iterable of (offset, size), any order."""
@@ -47,10 +72,13 @@ def make_buckets(offsets_sizes, total, bucket_elems):
 
 
 class GradReducer(object):
-    def __init__(self, grads, offsets_sizes, bucket_mb=64.0, group=None):
+    def __init__(self, grads, offsets_sizes, bucket_mb=64.0, group=None, always_reduce=False):
+        """``always_reduce``: issue the collectives even in a one-rank group (RCCL smoke tests on a single GPU)."""
         self.grads = grads
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if always_reduce and dist.is_initialized():
+            self.world = max(self.world, 2)          # only ever compared with 1: "there is a collective to run"
         self.buckets = make_buckets(offsets_sizes, grads.numel(), int(bucket_mb * 1024 * 1024 / 4))
         self.use_stream = grads.is_cuda
         # high priority: a bucket's collective should start as soon as its gradients are final, not queue behind backward kernels

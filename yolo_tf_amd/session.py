@@ -41,7 +41,7 @@ class TrainSession(object):
         self.optimizer = Optimizer(optimizer, config if config is not None else builder.config, e.n_params, dev)
         self.lr_fn = learning_rate_fn(config if config is not None else builder.config, learning_rate)
         self.gradient_clip = float(gradient_clip)
-        self.clip_ws = torch.zeros(e.n_seg, dtype=torch.float64, device=dev)
+        self.clip_ws = torch.zeros(ops.workspace_bytes('clip', e.n_seg) // 8, dtype=torch.float64, device=dev)
         self.global_step = 0
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
@@ -80,7 +80,7 @@ class TrainSession(object):
         if self.gradient_clip > 0:
             # [TF-sem] clip happens on the (averaged) gradient: scale first when data-parallel
             if self.world_size > 1:
-                e.grads.mul_(1.0 / self.world_size)
+                ops.scale(e.grads, e.n_params, 1.0 / self.world_size)
             ops.clip_by_norm(e.grads, e.seg_off, e.n_seg, self.gradient_clip, self.clip_ws)
             gscale = 1.0
         else:
@@ -131,7 +131,9 @@ class DetectSession(object):
         self.xy_max = torch.zeros(batch_size, n, 2, dtype=torch.float32, device=dev)
         self.order = torch.zeros(batch_size, n, dtype=torch.int32, device=dev)
         self.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.nms_ws = torch.zeros(batch_size * n * self.C, dtype=torch.int32, device=dev)
+        self._attrs = None
+        m.bind(self)                 # Model.conf / xy_min / xy_max / iou / prob / xy / wh read this session's buffers
+        self.nms_ws = torch.zeros(ops.workspace_bytes('nms', batch_size, n, self.C) // 4, dtype=torch.int32, device=dev)
 
     def run(self, images, preprocess_mode=0, check_numerics=True):
         """images: device f32 [B,H,W,3].  Returns device tensors conf [B,N,C], xy_min, xy_max [B,N,2]
@@ -140,12 +142,29 @@ class DetectSession(object):
         e.set_images(images, preprocess_mode)
         e.forward()
         logits, ld = e.act[e.output()]
+        self._attrs_valid = False
         self.nan_flag.zero_()
         ops.head_decode(logits, ld, self.anchors, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height,
                         m.cell_width, self.A, self.C)
         if check_numerics and int(self.nan_flag.item()) != 0:
             raise FloatingPointError('conf/xy_min/xy_max : Tensor had NaN or Inf values')
         return self.conf, self.xy_min, self.xy_max
+
+    def attrs(self):
+        """iou [B,N], prob [B,N,C], xy, wh [B,N,2] of the last run (model/yolo2/__init__.py:36-56), decoded on first use."""
+        if self._attrs is None:
+            dev = self.engine.device
+            self._attrs = {'iou': torch.zeros(self.B, self.N, dtype=torch.float32, device=dev),
+                           'prob': torch.zeros(self.B, self.N, self.C, dtype=torch.float32, device=dev),
+                           'xy': torch.zeros(self.B, self.N, 2, dtype=torch.float32, device=dev),
+                           'wh': torch.zeros(self.B, self.N, 2, dtype=torch.float32, device=dev)}
+            self._attrs_valid = False
+        if not getattr(self, '_attrs_valid', False):
+            e, m, a = self.engine, self.model, self._attrs
+            logits, ld = e.act[e.output()]
+            ops.head_decode_attrs(logits, ld, self.anchors, a['iou'], a['prob'], a['xy'], a['wh'], self.B, m.cell_height, m.cell_width, self.A, self.C)
+            self._attrs_valid = True
+        return self._attrs
 
     def nms(self, threshold=0.3, threshold_iou=0.4):
         """In-place batched NMS on the decoded boxes; returns order [B,N] (reference list order)."""

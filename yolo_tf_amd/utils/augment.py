@@ -146,7 +146,7 @@ class DeviceInputPipeline(object):
         cls_d = torch.from_numpy(np.resize(cls, n) if len(cls) else np.zeros(1, np.int32)).cuda()
         box_d = torch.from_numpy(box if len(box) else np.zeros((1, 4), np.float32)).cuda()
         first_d = torch.from_numpy(first).cuda()
-        self.err.zero_()
+        # the flag is sticky (the kernel ORs into it): check() reports a bad object of ANY batch since the last check
         ops.transform_labels(cls_d, box_d, first_d, *labels, self.B, self.classes, self.cell_width, self.cell_height, self.err)
         self._keep = (params, cls_d, box_d, first_d)      # alive until the next launch (asynchronous kernels)
         return self.out
@@ -158,6 +158,7 @@ class DeviceInputPipeline(object):
     def check(self):
         """Raises like the reference would (IndexError / AssertionError in transform_labels); synchronises."""
         e = int(self.err.item())
+        self.err.zero_()
         if e & 1:
             raise IndexError('transform_labels: object outside the grid or class id out of range')
         if e & 2:
