@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# two forward passes are compared below: the standalone statistics pass is order-independent (see test_network_gpu._dp_worker)
+os.environ['YOLO2_FUSE_BN_STATS'] = '0'
 
 import numpy as np
 import torch
@@ -32,7 +34,7 @@ def main():
     assert torch.equal(g, torch.arange(3_000_000, dtype=torch.float32, device='cuda'))     # SUM over one rank
     # 2. the whole data-parallel training step with its collectives routed through RCCL
     b, _ = make_builder('tiny', 20, 96, True, tempfile.mkdtemp(prefix='yolo_rccl_'))
-    sess = TrainSession(b, 2, dtype='bf16', optimizer='adam', learning_rate=1e-3, seed=3)
+    sess = TrainSession(b, 2, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=3)
     e = sess.engine
     rng = np.random.RandomState(0)
     images = torch.from_numpy(rng.uniform(0, 255, (2, 96, 96, 3)).astype(np.float32)).cuda()
@@ -45,8 +47,8 @@ def main():
     sess.apply_gradients()                      # consumes the buckets one by one as their all-reduces complete
     torch.cuda.synchronize()
     assert len(sess.reducer.done_events) == len(sess.reducer.buckets)
-    # bf16 + f32 atomics: the two backward passes agree to rounding, and the RCCL sum over one rank changes nothing
-    assert float((e.grads - local).abs().max()) <= 1e-3 * float(local.abs().max())
+    # f32 atomics: the two backward passes agree to rounding, and the RCCL sum over one rank changes nothing
+    assert float((e.grads - local).abs().max()) <= 1e-5 * float(local.abs().max())
     sync_replicas(sess, always=True)            # broadcast path (parameters, statistics, slots, global_step)
     assert sess.global_step == 1
     dist.barrier()

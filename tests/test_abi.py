@@ -14,6 +14,7 @@ def _declared():
 
 
 def test_library_exports_every_declared_symbol():
+    import torch  # noqa: F401  (one HIP runtime per process: torch's, see yolo_tf_amd/_lib.py load())
     from yolo_tf_amd.csrc import build
     path = build.build(verbose=False)
     lib = ctypes.CDLL(path)
@@ -53,6 +54,14 @@ def test_argument_errors_raise_without_touching_the_gpu():
         _lib.call('yolo2_conv2d', None, None, None, None, 1, 1, 1, 8, 8, 8, 8, 3, 0, None)
     with pytest.raises(_lib.HipKernelError):
         _lib.call('yolo2_nms', None, None, None, None, None, 1, 10, 2, 0.3, 0.4, None)
+
+
+def test_single_hip_runtime_after_load():
+    """Loading the C-ABI library must not map a second libamdhip64 next to torch's bundled one (stream ordering and pointer
+    validation both break across runtimes); _lib.load() imports torch first and checks."""
+    from yolo_tf_amd import _lib
+    _lib.load()
+    assert len(_lib._mapped_hip_runtimes()) == 1, _lib._mapped_hip_runtimes()
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -150,6 +150,14 @@ def test_detect_matches_oracle(basedir, inference, classes):
         if k.endswith('moving_variance'):
             params[k] = (rng.rand(*params[k].shape) + 0.5).astype(np.float32)
     params['conv/biases'] = (rng.randn(*params['conv/biases'].shape)).astype(np.float32)
+    if inference == 'tiny':
+        # the tiny plugin's truncated_normal(0.1) filters (reference model/yolo2/inference.py:33) amplify ~3000x through nine
+        # un-normalised layers in inference mode: exp() of the box logits overflows and check_numerics raises (correctly, and
+        # so would the reference).  Trained weights do not do that: use fan-in-scaled filters.
+        for k in list(params):
+            if k.endswith('/weights'):
+                kh, kw, cin, _ = params[k].shape
+                params[k] = (rng.randn(*params[k].shape) * np.sqrt(1.0 / (kh * kw * cin))).astype(np.float32)
     sess.engine.set_variables({scope + '/' + k: v for k, v in params.items()})
     images = rng.uniform(0, 255, (B, size, size, 3)).astype(np.float32)
     conf, mn, mx = [t.clone() for t in sess.run(torch.from_numpy(images).cuda())]
@@ -178,6 +186,18 @@ def test_detect_matches_oracle(basedir, inference, classes):
                     ctypes.c_long(classes), ctypes.c_float(thr), ctypes.c_float(0.4), o.ctypes.data_as(ctypes.POINTER(ctypes.c_long)))
         assert np.array_equal(sess.conf[i].cpu().numpy(), c)
         assert np.array_equal(order[i], o)
+
+
+def test_detect_raises_on_non_finite_outputs_like_check_numerics(basedir):
+    """detect.py:70 wraps the model outputs in tf.check_numerics: NaN/Inf raises.  The tiny plugin at its own initialisation
+    (truncated_normal(0.1) filters, identity moving statistics) overflows exp() of the box logits -- a natural way to force it."""
+    from yolo_tf_amd.session import DetectSession
+    b, _ = make_builder('tiny', 20, 96, False, basedir)
+    sess = DetectSession(b, 1, dtype='f32', seed=5)
+    images = torch.rand(1, 96, 96, 3, device='cuda') * 255
+    with pytest.raises(FloatingPointError, match='NaN or Inf'):
+        sess.run(images)
+    sess.run(images, check_numerics=False)          # the flag is advisory when the caller opts out (benchmarks)
 
 
 def test_postprocess_dropin_contract(golden_dir):
@@ -449,7 +469,7 @@ def test_backward_layerwise_teacher_forced(basedir, inference, size, dtype, B, c
     torch.cuda.synchronize()
     f32 = dtype == 'f32'
     q = (lambda a: a) if f32 else R.bf16_round
-    tol_vec, tol_l2 = (1e-4, 1e-4) if f32 else (1e-3, 2e-3)
+    tol_vec, tol_l2 = (1e-5, 1e-5) if f32 else (5e-4, 5e-4)       # measured worst: 1e-6 (f32), 1e-4 (bf16, conv20 dX at 416x416 batch 16)
     grads = strip(e.get_gradients(), scope)
 
     # ---- loss and its gradient on the GPU's own logits
@@ -521,7 +541,7 @@ def test_backward_layerwise_teacher_forced(basedir, inference, size, dtype, B, c
             r = rel_l2(dx, dx_ref)
             report.append((r, name + ' dX'))
             assert r <= tol_l2, '%s dX rel-L2 %.3e' % (name, r)
-            assert rel(dx, dx_ref) <= (1e-4 if f32 else 1.6e-2), '%s dX max err %.3e' % (name, rel(dx, dx_ref))
+            assert rel(dx, dx_ref) <= (1e-5 if f32 else 1.6e-2), '%s dX max err %.3e' % (name, rel(dx, dx_ref))
     report.sort(reverse=True)
     print('\n%s %d %s B%d C%d teacher-forced backward, worst: %s' % (inference, size, dtype, B, classes, ['%s %.1e' % (n, r) for r, n in report[:5]]))
 

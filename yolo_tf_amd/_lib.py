@@ -106,6 +106,14 @@ class FilterDesc(ctypes.Structure):
 _lib = None
 
 
+def _mapped_hip_runtimes():
+    try:
+        with open('/proc/self/maps') as f:
+            return sorted({line.split()[-1] for line in f if 'libamdhip64' in line})
+    except OSError:
+        return []
+
+
 def load():
     """Loads libyolo2hip.so and resolves every symbol of the header; raises if anything is missing."""
     global _lib
@@ -115,7 +123,15 @@ def load():
         raise HipKernelError(
             'HIP extension %s is missing: run `python yolo_tf_amd/csrc/build.py` (or __graft_entry__.build()). '
             'There is no CPU fallback.' % LIB_PATH)
+    # torch FIRST: its wheel bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  If this library were loaded before
+    # torch, it would bind /opt/rocm's copy and torch would then map a SECOND HIP runtime: two null streams with no ordering
+    # between torch's copies and these kernels, and device pointers one runtime allocated are unknown to the other's checked
+    # calls (hipMemsetAsync fails with "invalid value").  Loaded after torch, the dynamic linker reuses the runtime already mapped.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    runtimes = _mapped_hip_runtimes()
+    if len(runtimes) > 1:
+        raise HipKernelError('two HIP runtimes are mapped in this process (%s): something loaded %s before torch' % (', '.join(runtimes), LIB_PATH))
     for name, (res, args) in QUERIES.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.restype = res

@@ -46,8 +46,9 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
-        import ctypes
-        ctypes.CDLL(LIB)          # fails here (not on the GPU box) if any symbol is unresolved
+        # fails here (not on the GPU box) if any symbol is unresolved.  In a child process: dlopen()ing the library in THIS
+        # process before torch is imported would map a second HIP runtime next to torch's bundled one (see _lib.load)
+        subprocess.check_call([sys.executable, '-c', 'import ctypes, sys; ctypes.CDLL(sys.argv[1])', LIB])
     return LIB
 
 
