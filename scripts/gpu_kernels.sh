@@ -1,7 +1,11 @@
 #!/bin/bash
-# run on the GPU box: per-kernel parity tests (all of them, no -x) + device info
-mkdir -p gpurun_out
-rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/device.txt
-make -C oracle >/dev/null 2>&1
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -p no:cacheprovider 2>&1 | tail -150 > gpurun_out/kernels.log
-tail -40 gpurun_out/kernels.log
+# Kernel iteration call: the conv parity tests, then the per-layer microbench under each configuration line of $1 (default below).
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -x -k "${TESTK:-conv or wgrad}" -p no:cacheprovider 2>&1 | tail -5
+CFG=${1:-scripts/kernel_cfgs.txt}
+: > gpurun_out/conv_bench.log
+while IFS= read -r cfg; do
+  [ -z "$cfg" ] && continue
+  env $cfg timeout 300 python scripts/conv_bench.py "$cfg" 2>/dev/null | tee -a gpurun_out/conv_bench.log
+done < $CFG

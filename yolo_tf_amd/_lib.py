@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libyolo2hip.so')
+LIB_PATH = os.environ.get('YOLO2_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libyolo2hip.so')     # the override is for timing-ablation builds (scripts/abl_build.sh)
 
 F32, BF16 = 0, 1
 

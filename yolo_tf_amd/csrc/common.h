@@ -12,7 +12,43 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
 void yolo2_set_error(const char *fmt, ...);
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ds_read_b64_tr_b16 through inline asm.  The builtin form is a compiler-visible LDS read: while an LDS-DMA (buffer_load ... lds)
+// is in flight hipcc 7.2 puts `s_waitcnt vmcnt(0)` in front of every such read (it cannot tell the DMA's destination from the
+// read's address), which drains the whole DMA ring each K step -- measured in round 1's filter-gradient kernel, whose counted
+// vmcnt waits never had anything left to count.  An asm read is invisible to that pass; its completion is waited for by hand
+// with y2_lgkm_wait*, whose "+v" operands tie the wait to the destination registers (nothing that uses them can be scheduled
+// above it; cdna_hip_programming.md section 5.7 form (ii)).  LDS reads of one wave return in order.
+__device__ __forceinline__ u32x2 y2_tr16_read(unsigned lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 y2_tr16_read_off(unsigned lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
+// wait until at most N LDS operations of this wave are outstanding; a, b (and c, d): the registers whose data this wait covers
+template <int N> __device__ __forceinline__ void y2_lgkm_wait2(u32x2 &a, u32x2 &b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void y2_lgkm_wait4(u32x2 &a, u32x2 &b, u32x2 &c, u32x2 &d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+__device__ __forceinline__ bf16x8 y2_frag16(u32x2 lo, u32x2 hi) {
+    const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ unsigned y2_lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+#endif
 
 // first-layer direct convolution (conv_first.hip), used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches
 bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize);

@@ -62,6 +62,19 @@ template <> struct Mma<float> {
     }
 };
 
+// Timing-ablation builds only (scripts/abl_build.sh -> a separate .so, never the product): bit 0 no epilogue, 1 no statistics
+// atomics, 2 no MFMA, 3 no fragment reads (and no MFMA), 4 no operand DMA.  0 in every shipped build.
+#ifndef Y2_ABL
+#define Y2_ABL 0
+#endif
+#if Y2_ABL          // (bf16 only: hipcc 7.2 drops the host stub of one f32 instantiation in some ablated bodies)
+#undef Y2_DISPATCH_DTYPE
+#define Y2_DISPATCH_DTYPE(dtype, ...)                                   \
+    do {                                                                \
+        if ((dtype) == YOLO2_BF16) { typedef bf16 T; __VA_ARGS__; }     \
+        else { yolo2_set_error("ablation build: bf16 only"); return YOLO2_E_ARG; } \
+    } while (0)
+#endif
 #define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
@@ -71,7 +84,7 @@ template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAI
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags, float act_alpha) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags, float act_alpha, int wide_store) {
     constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
@@ -213,13 +226,21 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             bool ok = (a_mask[i] & tapbit) != 0;
             if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
             const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
+#if !(Y2_ABL & 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
+#else
+            asm volatile("" ::"v"(voff));
+#endif
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
             if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
+#if !(Y2_ABL & 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
+#else
+            asm volatile("" ::"v"(voff));
+#endif
         }
         ++kt_issue;
         i_stage = (i_stage + 1 == NSTAGE) ? 0 : i_stage + 1;
@@ -262,17 +283,29 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+#if Y2_ABL & 8
+                asm volatile("" : "=v"(af[i]));
+#else
                 af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
+#endif
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+#if Y2_ABL & 8
+                asm volatile("" : "=v"(bf[j]));
+#else
                 bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
+#endif
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+#if Y2_ABL & 12
+                    asm volatile("" ::"v"(af[i]), "v"(bf[j]));
+#else
                     acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
+#endif
                 }
         }
     }
@@ -287,16 +320,24 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         unsigned *flags = sk_flags;       // library-owned, all zero between launches (each flag is cleared by its consumer)
         float *slots = Oacc;
         constexpr int SLOT = BM * BN;
+        // Slots are written and read 16 bytes per lane with sc1 buffer accesses: a dword sc1 store is one fabric write each
+        // (~6x the time per byte of a dwordx4 one), and the 22..54 MB of parked partials per launch were a fifth of the
+        // long-reduction launches.  Slot image = accumulator registers in groups of four: [group][lane][4].
+        const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const unsigned slot_lane = (unsigned)(((size_t)wave * (TM * TN * 16 * 64) + (size_t)lane * 4) * sizeof(float));
         if (kt_beg > 0) {
-            float *mine = slots + (size_t)wx * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
+            const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        __hip_atomic_store(mine + ((i * TN + j) * 16 + r) * 64, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // Agent-scope relaxed accesses (sc1: written through / read past the non-coherent per-XCD L2) instead of
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcS, mine + ((i * TN + j) * 4 + q4) * 1024, 0, 16);
+                    }
+            // Agent-scope write-through accesses (sc1: written through / read past the non-coherent per-XCD L2) instead of
             // release/acquire fences: an agent-scope fence writes back and invalidates the whole XCD L2, which evicts the
             // filter slabs and input tiles every other workgroup of the XCD is streaming (measured: +100 us per launch).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's slot stores have been acknowledged
@@ -314,13 +355,19 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                     __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exactly one consumer per flag
                 }
                 __syncthreads();
-                const float *theirs = slots + (size_t)p * SLOT + (size_t)wave * (TM * TN * 16 * 64) + lane;
+                const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += __hip_atomic_load(theirs + ((i * TN + j) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, theirs + ((i * TN + j) * 4 + q4) * 1024, 0, 16));
+                            acc[i][j][4 * q4] += v[0];
+                            acc[i][j][4 * q4 + 1] += v[1];
+                            acc[i][j][4 * q4 + 2] += v[2];
+                            acc[i][j][4 * q4 + 3] += v[3];
+                        }
                 covered = (long)(p + 1) * su_total / G;
             }
         }
@@ -370,8 +417,67 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
         }
     };
-    if (m0 + BM <= M) write_tile(std::false_type{});
+    // Wide-store epilogue.  The accumulator layout puts ONE output element per lane per register: storing straight from it is
+    // 16*TM*TN two-byte stores per lane, and the store queue, not HBM, bounded the short-reduction layers (a 128x128x576 tile is
+    // 4.6k MFMA cycles; its 32 narrow store instructions per wave took longer than that).  Instead each wave rounds its
+    // sub-tile into a private, padded LDS image (the DMA ring is idle by now), computes the statistics from the rounded values
+    // on the way, and reads it back row-major: 16 bytes (8 bf16 / 4 f32 consecutive filters of one pixel) per lane per store.
+#if Y2_ABL & 1      // a run-time-false guard keeps the accumulators live (an inline-asm use of a 16-float vector makes hipcc 7.2 drop the host stub)
+    if (act_alpha == 7777.0f)
+#endif
+    {
+    constexpr int WROWS = TM * 32, WROWB = TN * 32 * (int)sizeof(T), WSTRIDE = WROWB + 16, WCPR = WROWB / 16;
+    constexpr bool WIDE_FITS = SPLITK != 1 && NW * WROWS * WSTRIDE <= NSTAGE * STAGE;
+    if (WIDE_FITS && wide_store) {
+        __syncthreads();                       // every wave has finished reading the last K step's stage
+        unsigned char *wreg = smem + wave * (WROWS * WSTRIDE);
+        const bool tail = m0 + BM > M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const bool n_ok = n < Nf;
+            const float bv = (bias && n_ok) ? bias[n] : 0.f;
+            const float sh = (stats && n_ok) ? bn_shift[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv;
+                    if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
+                    const T o = (T)v;
+                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane & 31)) * (int)sizeof(T)) = o;
+                    if (stats && (!tail || m0 + wm * WROWS + row < M)) {
+                        const float d = (float)o - sh;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                }
+            }
+            if (stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32 && n_ok && !(Y2_ABL & 2)) {
+                    const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                    unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
+                    unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
+                }
+            }
+        }
+        // (LDS operations of one wave execute in order: its own reads below see its own writes above)
+#pragma unroll
+        for (int it = 0; it < WROWS * WCPR / 64; ++it) {
+            const int id = it * 64 + lane;
+            const int row = id / WCPR, ch = id % WCPR;
+            const int m = m0 + wm * WROWS + row;
+            const int n = n0 + wn * TN * 32 + ch * VEC;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
+            if (m < M && n < Nf) *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+        }
+    } else if (m0 + BM <= M) write_tile(std::false_type{});
     else write_tile(std::true_type{});
+    }
     if (SPLITK != 2) break;
   }
 }
@@ -466,7 +572,7 @@ static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
         for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
         conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<g_, NWv * 64, 0, st>>>(          \
-            (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha); \
+            (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha, wide_store); \
     } while (0)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
@@ -498,6 +604,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     const unsigned f_bytes = (unsigned)((size_t)Nf * ksize * ksize * Cp * sizeof(T));
     const bool ctail = (Cp % BK) != 0;
     unsigned *sk_flags = nullptr;
+    // 16-byte epilogue stores need 16-byte aligned pixel rows, and a partial last chunk may only spill into this tensor's own
+    // padding lanes (written as zeros), never into a neighbouring concat slice
+    static const int env_wide = getenv("YOLO2_IGEMM_WIDE_STORE") ? atoi(getenv("YOLO2_IGEMM_WIDE_STORE")) : 1;
+    const int wide_store = env_wide && ((uintptr_t)O & 15) == 0 && ldo % VEC == 0 && (Nf % VEC == 0 || ldo < Nf + VEC);
     // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
     const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
     const int MT2 = cdiv(M, 256), NT2 = cdiv(Nf, 128);

@@ -188,36 +188,60 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         const unsigned char *Xs = smem + c_stage * STAGE;
         const unsigned char *Ys = Xs + XBYTES;
         c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+        if constexpr (sizeof(T) == 2 && VARIANT == 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // hardware transpose read: lane (g,t) supplies the address of pixel row (t>>2), channel quad (t&3) of its group's
+            // 4x16 block and receives 4 pixels of channel t.  Issued through inline asm (common.h y2_tr16_read): the builtin form
+            // made hipcc put `s_waitcnt vmcnt(0)` in front of the first read of every tile -- the DMA ring was drained each
+            // iteration and the counted vmcnt above never had anything to count.  All reads of the tile are issued first, each K
+            // step's MFMAs wait only for their own fragments.
+            constexpr int KSN = BKP / 16;
+            u32x2 ra[KSN][TM][2], rb[KSN][TN][2];
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t >> 2);
+                    const int co = 16 * (g & 1) + 4 * (t & 3);               // channel offset inside a 32-wide MFMA tile
+                    const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int ch = (wm * TM + i) * 32 + co;
+                        ra[ks][i][r] = y2_tr16_read(y2_lds_addr(Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1)));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int ch = (wn * TN + j) * 32 + co;
+                        rb[ks][j][r] = y2_tr16_read(y2_lds_addr(Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1)));
+                    }
+                }
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) {
+                constexpr int PER = 2 * (TM + TN);                         // reads per K step
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (ks == 0 && KSN == 2) y2_lgkm_wait2<PER>(ra[ks][i][0], ra[ks][i][1]);
+                    else if (ks + 2 == KSN) y2_lgkm_wait2<PER>(ra[ks][i][0], ra[ks][i][1]);
+                    else y2_lgkm_wait2<0>(ra[ks][i][0], ra[ks][i][1]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (ks + 2 == KSN) y2_lgkm_wait2<PER>(rb[ks][j][0], rb[ks][j][1]);
+                    else y2_lgkm_wait2<0>(rb[ks][j][0], rb[ks][j][1]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y2_frag16(ra[ks][i][0], ra[ks][i][1]), y2_frag16(rb[ks][j][0], rb[ks][j][1]), acc[i][j], 0, 0, 0);
+            }
+#endif
+        } else {
 #pragma unroll
         for (int ks = 0; ks < BKP / KSTEP; ++ks) {
             if constexpr (sizeof(T) == 2) {
                 bf16x8 af[TM], bf[TN];
-                if constexpr (VARIANT == 0) {
-                    // hardware transpose read: lane (g,t) supplies the address of pixel row (t>>2), channel quad
-                    // (t&3) of its group's 4x16 block and receives 4 pixels of channel t
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t >> 2);
-                        const int co = 16 * (g & 1) + 4 * (t & 3);               // channel offset inside a 32-wide MFMA tile
-                        const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) {
-                            const int ch = (wm * TM + i) * 32 + co;
-                            const unsigned char *p = Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1);
-                            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
-                            bf16x4 b = __builtin_bit_cast(bf16x4, v);
-                            af[i][4 * r + 0] = b[0]; af[i][4 * r + 1] = b[1]; af[i][4 * r + 2] = b[2]; af[i][4 * r + 3] = b[3];
-                        }
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) {
-                            const int ch = (wn * TN + j) * 32 + co;
-                            const unsigned char *p = Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1);
-                            s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
-                            bf16x4 b = __builtin_bit_cast(bf16x4, v);
-                            bf[j][4 * r + 0] = b[0]; bf[j][4 * r + 1] = b[1]; bf[j][4 * r + 2] = b[2]; bf[j][4 * r + 3] = b[3];
-                        }
-                    }
-                } else {
+                {
                     // reference gather (slow, layout-proof): 8 scalar LDS reads per fragment
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -263,6 +287,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
         }
     }
 
+        }
     // epilogue: rows = input channels c, cols = filters n; dW is HWIO [tap][Cin][Cout]
     // PAIR: WGM = 2 and TM = 1, so wave row wm holds exactly one tap of the pair (rows 32*wm .. 32*wm+31 = its 32 channels)
     const int my_tap = PAIR ? tap + wm : tap;
@@ -368,7 +393,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     }
     if constexpr (BC >= 128) {
         if (g_wgrad_variant == 0 && nw8) {
-            conv_wgrad_kernel<T, BC, BNN, 0, 8><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
+            conv_wgrad_kernel<T, BC, BNN, 0, 8, BKPv><<<grid, 512, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
             return;
         }
     }
@@ -379,7 +404,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
         }
     }
     if (g_wgrad_variant == 0)
-        conv_wgrad_kernel<T, BC, BNN, 0><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
+        conv_wgrad_kernel<T, BC, BNN, 0, 4, BKPv><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
     else
         conv_wgrad_kernel<T, BC, BNN, 1><<<grid, 256, 0, st>>>((const T *)X, x_bytes, (const T *)dY, y_bytes, dW, H, W, Cin, ldx, Cout, ldy, ksize, M, CT, NT, mchunk, remap, direct);
 }
