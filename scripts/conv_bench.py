@@ -17,10 +17,32 @@ T = torch.bfloat16
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
 
 
+GRAPH = os.environ.get('GRAPH', '1') != '0'
+
+
 def timeit(fn, n=10):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if GRAPH:
+        # 20 launches captured in one graph: the replay is not bounded by the ~10 us per launch the Python/ctypes host path costs
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(20):
+                    fn()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            g.replay()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 60 * 1e3
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n):

@@ -377,6 +377,10 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     // sum(y - shift), sum((y - shift)^2) of the STORED (rounded) outputs to one of Y2_BN_PART_ROWS partial rows: the
     // statistics pass over y (a full re-read of every activation, 21 launches per step) is gone.
     const bool stats = SPLITK != 1 && bn_part != nullptr;
+    // The partial rows are indexed by (pixel tile, wave row).  When those fit the 256 rows every (row, filter) has exactly one writer:
+    // plain stores, bitwise-reproducible statistics -- and the f32 atomics of the 13x13 stages (each a fabric round trip) were 10 us of
+    // a 77 us launch (profiles/r02_igemm_ablation.txt).  Larger layers wrap around the rows and keep the atomic adds.
+    const bool stats_unique = MT * WGM <= Y2_BN_PART_ROWS;
     auto write_tile = [&](auto checked_tag) {      // interior tiles skip the per-element row test (one VALU compare + branch each)
         constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -411,8 +415,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32) {
                     const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
-                    unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
-                    unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
+                    float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
+                    if (stats_unique) { *p1 = s1; *p2 = s2; }
+                    else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
                 }
             }
         }
@@ -460,8 +465,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32 && n_ok && !(Y2_ABL & 2)) {
                     const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
-                    unsafeAtomicAdd(bn_part + (long)slot * Nf + n, s1);
-                    unsafeAtomicAdd(bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n, s2);
+                    float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
+                    if (stats_unique) { *p1 = s1; *p2 = s2; }      // one writer per (row, filter): a store into the zeroed row
+                    else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
                 }
             }
         }
