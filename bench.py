@@ -196,6 +196,7 @@ def main():
     ap.add_argument('--names', type=int, default=20, choices=[20, 80])
     ap.add_argument('--size', type=int, default=416)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--multiscale', action='store_true', help='BASELINE configs[3]: a different input size {320..608} every step (batch defaults to 8 per GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
@@ -228,6 +229,8 @@ def main():
     from yolo_tf_amd.session import TrainSession
     from yolo_tf_amd.utils import data
     basedir = tempfile.mkdtemp(prefix='yolo_bench_%d_' % rank)
+    if args.multiscale:
+        return multiscale(args, rank, world, basedir, dist)
     builder, cfg = make_builder('darknet', args.names, args.size, True, basedir)
     sess = TrainSession(builder, args.batch, dtype=args.dtype, optimizer='adam', learning_rate=1e-6, seed=0, world_size=world,
                         bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'))
@@ -314,6 +317,63 @@ def main():
             torch.cuda.empty_cache()
             out['detect'] = detect_latency(args, basedir)
         print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def multiscale(args, rank, world, basedir, dist):
+    """BASELINE configs[3]: Darknet-19 multi-scale training, input size drawn from {320, 352, ..., 608} per step (here: cycled, so
+    that every run does the same work), one set of weights, buffers allocated once for 608x608.  Weak scaling over ranks."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    sizes = list(range(320, 609, 32))
+    batch = args.batch if '--batch' in sys.argv else 8
+    builder, cfg = make_builder('darknet', args.names, 416, True, basedir)
+    sess = TrainSession(builder, batch, dtype=args.dtype, optimizer='adam', learning_rate=1e-6, seed=0, world_size=world,
+                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'), sizes=[(s, s) for s in sizes])
+    gen = torch.Generator(device='cuda').manual_seed(1234 + rank)
+    images = {}
+    for sz in sizes:
+        sess.set_size(sz, sz)
+        images[sz] = torch.rand(batch, sz, sz, 3, device='cuda', generator=gen) * 255.0
+        sess.upload_labels(data.synthetic_batch(batch, args.names, sz // 32, sz // 32, seed=4321 + rank + sz))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run(n):
+        for i in range(n):
+            sz = sizes[i % len(sizes)]
+            sess.set_size(sz, sz)
+            sess.step(images[sz])
+
+    run(max(args.warmup, len(sizes)))            # every size once before the clock starts (plans, filter layouts)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = sess.fetch()
+    if rank == 0:
+        gflop = sum(TRAIN_GFLOP_PER_IMG[args.names] * (sizes[i % len(sizes)] / 416.0) ** 2 for i in range(args.steps)) * batch * world
+        peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == 'bf16' else F32_MATRIX_PEAK_TFLOPS
+        print(json.dumps({
+            'metric': 'train_throughput', 'value': world * batch * args.steps / elapsed, 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': max(args.warmup, len(sizes)), 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Darknet-19 YOLOv2 multi-scale training, input size cycled over %s, batch %d per GPU (BASELINE configs[3])' % (sizes, batch),
+                       'global_batch': world * batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)'},
+            'whole_step_tflops': gflop / elapsed / 1e3, 'whole_step_frac_of_mfma_peak': gflop / elapsed / 1e3 / peak / world,
+            'total_loss': loss['total_loss']}), flush=True)
     barrier()
     if world > 1:
         dist.destroy_process_group()

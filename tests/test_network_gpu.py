@@ -553,3 +553,80 @@ def test_backward_layerwise_teacher_forced(basedir, inference, size, dtype, B, c
         w_ref, _, _ = R.adam_step(params0[k], g_dev[k], np.zeros_like(params0[k]), np.zeros_like(params0[k]), lr, 1)
         err = np.abs(params1[k] - w_ref)
         assert np.all(err <= 2.4e-7 * np.abs(w_ref) + 1e-4 * lr), (k, float(err.max()))
+
+
+def test_multi_scale_training_matches_oracle_per_size(basedir):
+    """BASELINE configs[3] (multi-scale {320..608}; the reference lists it as future work, README.md:87): ONE session, buffers
+    allocated for 608x608, per-step input size switched with set_size.  At 352 and 320 (cells 11 / 10, reorg input 22 / 20) the
+    forward, the loss and the gradients match the oracle on the same weights; 608 runs the largest binding; returning to a size
+    reproduces its first result (weights untouched in between: forward_backward only)."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    classes, B = 20, 1
+    b, _ = make_builder('darknet', classes, 320, True, basedir)
+    sess = TrainSession(b, B, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=4, sizes=[(352, 352), (608, 608), (320, 320)])
+    e = sess.engine
+    scope = 'yolo2_darknet'
+    params0 = strip(e.get_variables(), scope)
+    rng = np.random.RandomState(8)
+    for k in list(params0):
+        if k.endswith('gamma'):
+            params0[k] = (rng.rand(*params0[k].shape) + 0.5).astype(np.float32)
+        if k.endswith(('beta', 'biases')):
+            params0[k] = (rng.randn(*params0[k].shape) * 0.1).astype(np.float32)
+    e.set_variables({scope + '/' + k: v for k, v in params0.items()})
+    spec = R.darknet_spec(classes, len(b.anchors))
+    first = {}
+    for size in (352, 320, 608, 352, 320):
+        cells = size // 32
+        sess.set_size(size, size)
+        assert (sess.model.cell_width, sess.model.cell_height) == (cells, cells)
+        irng = np.random.RandomState(size)
+        images = irng.uniform(0, 255, (B, size, size, 3)).astype(np.float32)
+        labels = data.synthetic_batch(B, classes, cells, cells, seed=size)
+        sess.upload_labels(labels)
+        sess.forward_backward(torch.from_numpy(images).cuda())
+        got = sess.fetch()
+        out = e.output()
+        assert (out.h, out.w) == (cells, cells)
+        logits = read_t(e, out)
+        grads = strip(e.get_gradients(), scope)
+        assert torch.all(e.act[out][0].float().reshape(-1, 128)[:B * cells * cells, 125:] == 0)          # padding lanes stay zero
+        if size in first:
+            # (the 26x26 / 52x52 stages accumulate statistics and filter gradients with f32 atomics: order-dependent last bits)
+            assert abs(got['total_loss'] - first[size][0]) <= 1e-5 * abs(first[size][0])
+            assert rel(logits, first[size][1]) <= 1e-4
+            continue
+        first[size] = (got['total_loss'], logits.copy())
+        x = np.stack([R.per_image_standardization(i) for i in images]).astype(np.float32)
+        net, caches = R.network_forward(spec, params0, x, training=True)
+        m = R.model_decode(net, classes, b.anchors, training=True)
+        obj, aux = R.objectives(m, labels)
+        loss = float(R.total_loss(obj, HP))
+        assert rel(logits, net) <= 1e-4, (size, rel(logits, net))
+        assert abs(got['total_loss'] - loss) <= 1e-4 * abs(loss), (size, got['total_loss'], loss)
+        if size != 608:          # (the 608 oracle backward is ~20 s of host time for no new code path)
+            ref = R.network_backward(spec, params0, caches, R.loss_backward(m, labels, aux, HP, classes))
+            cs = min(cosine(grads[k], ref[k]) for k in grads)
+            assert cs >= 0.9995, (size, cs)
+
+
+def test_multi_scale_bf16_training_steps(basedir):
+    """The benchmarked form of configs[3]: bf16, batch 8, a different input size every step, one set of weights: the loss is
+    finite at every size and the moving statistics / weights keep evolving through the switches."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B, classes = 8, 20
+    sizes = [320, 416, 608, 352, 544]
+    b, _ = make_builder('darknet', classes, 416, True, basedir)
+    sess = TrainSession(b, B, dtype='bf16', optimizer='adam', learning_rate=1e-4, seed=1, sizes=[(s, s) for s in sizes])
+    g = torch.Generator(device='cuda').manual_seed(3)
+    before = sess.engine.params.clone()
+    for it, size in enumerate(sizes * 2):
+        sess.set_size(size, size)
+        sess.upload_labels(data.synthetic_batch(B, classes, size // 32, size // 32, seed=it))
+        sess.step(torch.rand(B, size, size, 3, device='cuda', generator=g) * 255)
+        loss = sess.fetch()['total_loss']
+        assert np.isfinite(loss) and 0 < loss < 10, (size, loss)
+    assert sess.global_step == 2 * len(sizes)
+    assert torch.isfinite(sess.engine.params).all() and float((sess.engine.params - before).abs().max()) > 0

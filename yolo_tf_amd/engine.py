@@ -121,22 +121,16 @@ class Engine(object):
 
     # ---------------------------------------------------------------- activations
     def _alloc_activations(self):
+        """Root buffers (by tensor NAME, sized for the graph the engine is built with -- the largest input size of a multi-scale
+        run) and per-layer state; then the first binding.  Activations are flat [B*h*w][ld] images, so a smaller input size uses a
+        prefix of every buffer and the padding lanes (index mod ld >= c) sit at the same flat positions for every size."""
         B, T, dev = self.B, self.dtype, self.device
-        self.act, self.gact = {}, {}
-        roots = {}
+        self._roots, self._groots = {}, {}
         for t in self.graph.tensors:
             if t.base is None:
-                roots[t] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
-        groots = {}
-        if self.training:
-            for t in self.graph.tensors:
-                if t.base is None and t not in self.graph.inputs.values():
-                    groots[t] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
-        for t in self.graph.tensors:
-            r, off, ld = t.storage()
-            self.act[t] = (roots[r][off:], ld)
-            if r in groots:
-                self.gact[t] = (groots[r][off:], ld)
+                self._roots[t.name] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
+                if self.training and t not in self.graph.inputs.values():
+                    self._groots[t.name] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
         self.conv = {}
         max_y = 0
         max_c = 8
@@ -154,23 +148,9 @@ class Engine(object):
             self.conv[op['name']] = st
             max_y = max(max_y, B * op['out'].h * op['out'].w * ldy)
             max_c = max(max_c, ldy)
-        # BN + leaky + max-pool fusion: a batch-normalised conv whose output feeds one stride-2 pool and nothing else never
-        # materialises its full-resolution activation (forward) or that activation's gradient (backward)
-        self.fused_pool = {}
-        if os.environ.get('YOLO2_FUSE_POOL', '1') != '0':
-            uses = {}
-            for op in self.graph.ops:
-                for t in (op.get('inputs') or [op['x']]):
-                    uses[t] = uses.get(t, 0) + 1
-            producers = {op['out']: op for op in self.graph.ops if op['kind'] == 'conv'}
-            for op in self.graph.ops:
-                x = op.get('x')
-                if (op['kind'] == 'pool' and op['stride'] == 2 and x in producers and producers[x]['bn'] and uses.get(x, 0) == 1
-                        and x.h % 2 == 0 and x.w % 2 == 0 and self.act[x][1] == x.c and self.act[op['out']][1] == op['out'].c
-                        and self.act[producers[x]['y']][1] == x.c and x.c // (8 if T == torch.bfloat16 else 4) <= 256):
-                    self.fused_pool[x] = op
-                    if self.training:
-                        self.conv[producers[x]['name']]['pool_idx'] = torch.zeros(B * (x.h // 2) * (x.w // 2) * x.c, dtype=torch.uint8, device=dev)
+        self._bindings = {}
+        self._tmp_roots = {}
+        self._bind(self.graph)
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
         self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
@@ -191,8 +171,63 @@ class Engine(object):
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
             self.side_stream = torch.cuda.Stream(device=dev)
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
-            self.tmp_grad = {}
         self.img = None
+
+    def _bind(self, graph):
+        """Views of the root buffers for one traced input size + the shape-dependent plans; makes it the current binding."""
+        B, T, dev = self.B, self.dtype, self.device
+        act, gact = {}, {}
+        for t in graph.tensors:
+            r, off, ld = t.storage()
+            root = self._roots[r.name]
+            assert B * r.h * r.w * r.ld <= root.numel(), 'input size exceeds the one the engine was allocated for (%s)' % r.name
+            act[t] = (root[off:], ld)
+            if r.name in self._groots:
+                gact[t] = (self._groots[r.name][off:], ld)
+        # BN + leaky + max-pool fusion: a batch-normalised conv whose output feeds one stride-2 pool and nothing else never
+        # materialises its full-resolution activation (forward) or that activation's gradient (backward)
+        fused_pool = {}
+        if os.environ.get('YOLO2_FUSE_POOL', '1') != '0':
+            uses = {}
+            for op in graph.ops:
+                for t in (op.get('inputs') or [op['x']]):
+                    uses[t] = uses.get(t, 0) + 1
+            producers = {op['out']: op for op in graph.ops if op['kind'] == 'conv'}
+            for op in graph.ops:
+                x = op.get('x')
+                if (op['kind'] == 'pool' and op['stride'] == 2 and x in producers and producers[x]['bn'] and uses.get(x, 0) == 1
+                        and x.h % 2 == 0 and x.w % 2 == 0 and act[x][1] == x.c and act[op['out']][1] == op['out'].c
+                        and act[producers[x]['y']][1] == x.c and x.c // (8 if T == torch.bfloat16 else 4) <= 256):
+                    fused_pool[x] = op
+                    st = self.conv[producers[x]['name']]
+                    need = B * (x.h // 2) * (x.w // 2) * x.c
+                    if self.training and ('pool_idx' not in st or st['pool_idx'].numel() < need):
+                        st['pool_idx'] = torch.zeros(need, dtype=torch.uint8, device=dev)
+        inp = next(iter(graph.inputs.values()))
+        self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {}}
+        self._use(inp.h, inp.w)
+
+    def _use(self, h, w):
+        bnd = self._bindings[(h, w)]
+        self._cur = bnd
+        self.graph, self.act, self.gact, self.fused_pool = bnd['graph'], bnd['act'], bnd['gact'], bnd['fused_pool']
+        self._zero_ranges, self.tmp_grad = bnd['zero_ranges'], bnd['tmp_grad']
+
+    def add_size(self, graph):
+        """Multi-scale training (BASELINE configs[3]): binds another traced input size of the SAME network (same variables, any
+        size not larger than the construction-time one) to the same buffers."""
+        names = [v.name for v in graph.variables.values()]
+        assert names == [v.name for v in self._bindings[next(iter(self._bindings))]['graph'].variables.values()], 'different network'
+        cur = self._cur
+        self._bind(graph)
+        self._cur = cur
+        self._use(*[k for k, v in self._bindings.items() if v is cur][0])
+
+    def set_size(self, height, width):
+        """Switches every following forward / backward to a bound input size; parameters, statistics and optimizer state are shared."""
+        if (height, width) not in self._bindings:
+            raise KeyError('input size %dx%d was not bound (Engine.add_size)' % (height, width))
+        self._use(height, width)
 
     # ---------------------------------------------------------------- helpers
     def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k, bn_shift=None):
@@ -291,7 +326,7 @@ class Engine(object):
 
     def zero_grads(self):
         if self._zero_ranges is None:
-            self._zero_ranges = self._plan_grad_zeroing()
+            self._zero_ranges = self._cur['zero_ranges'] = self._plan_grad_zeroing()
         if self._zero_ranges:
             ops.zero_ranges(self.grads, self._zero_ranges)
 
@@ -360,7 +395,11 @@ class Engine(object):
             return gb, ld, None
         tmp = self.tmp_grad.get(t)
         if tmp is None:
-            tmp = self.tmp_grad[t] = torch.zeros(self.B * t.h * t.w * ld, dtype=self.dtype, device=self.device)
+            n = self.B * t.h * t.w * ld
+            root = self._tmp_roots.get(t.name)          # shared between input sizes (a prefix serves the smaller ones)
+            if root is None or root.numel() < n:
+                root = self._tmp_roots[t.name] = torch.zeros(n, dtype=self.dtype, device=self.device)
+            tmp = self.tmp_grad[t] = root
         n = self.B * t.h * t.w * ld
         return tmp, ld, (lambda: ops.add_inplace(gb, tmp, n))
 

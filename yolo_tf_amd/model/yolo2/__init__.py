@@ -99,6 +99,16 @@ class Builder(yolo.Builder):
         self.model = Model(self.output, len(self.names), self.anchors, training=training)
         return self.model
 
+    def trace(self, width, height, training=False):
+        """Traces the same network at another input size (multi-scale training, BASELINE configs[3]; the reference lists it as
+        future work, README.md:87): returns (graph, Model) without touching the builder's own graph / model."""
+        dw, dh = getattr(inference, self.config.get(__name__.split('.')[-1], 'inference').upper() + '_DOWNSAMPLING')
+        assert width % dw == 0 and height % dh == 0, 'input size must be a multiple of the downsampling (%d, %d)' % (dw, dh)
+        graph = G.Graph()
+        data = G.placeholder(graph, 'image', height, width)
+        _, output = self.func(data, len(self.names), len(self.anchors), training=training)
+        return graph, Model(output, len(self.names), self.anchors, training=training)
+
     def create_objectives(self, labels=(None,) * 6):
         section = __name__.split('.')[-1]
         self.objectives = Objectives(self.model, *labels)

@@ -23,20 +23,36 @@ class TrainSession(object):
     per-tensor clip -> optimizer; all asynchronous on the current stream."""
 
     def __init__(self, builder, batch_size, dtype='bf16', optimizer='adam', learning_rate=1e-6, gradient_clip=0.0,
-                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0):
+                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None):
+        """``sizes``: optional list of (width, height) input sizes for multi-scale training (BASELINE configs[3]); buffers are
+        allocated once for the largest, ``set_size`` switches between them, the builder's configured size is selected first."""
         assert builder.training, 'call builder(data, training=True) first'
         self.builder = builder
-        self.model = builder.model
-        self.engine = Engine(builder.graph, batch_size, dtype, training=True, seed=seed)
-        e = self.engine
         self.B = batch_size
-        m = self.model
-        self.A, self.C = len(m.anchors), m.classes
+        own = (builder.width, builder.height)
+        traced = {own: (builder.graph, builder.model)}
+        for wh in (sizes or []):
+            wh = (int(wh[0]), int(wh[1]))
+            if wh not in traced:
+                traced[wh] = builder.trace(wh[0], wh[1], training=True)
+        largest = max(traced, key=lambda wh: wh[0] * wh[1])
+        assert all(w <= largest[0] and h <= largest[1] for w, h in traced), 'one size must contain all the others'
+        self.engine = Engine(traced[largest][0], batch_size, dtype, training=True, seed=seed)
+        e = self.engine
+        self.models = {wh: gm[1] for wh, gm in traced.items()}
+        m0 = traced[largest][1]
+        self.A, self.C = len(m0.anchors), m0.classes
         dev = e.device
-        self.anchors = torch.from_numpy(m.anchors.reshape(-1)).to(dev)
-        self.labels = [torch.zeros(*s, dtype=torch.float32, device=dev) for s in _label_shapes(batch_size, m.cells, self.C)]
+        self.anchors = torch.from_numpy(m0.anchors.reshape(-1)).to(dev)
+        self._labels = {wh: [torch.zeros(*s, dtype=torch.float32, device=dev) for s in _label_shapes(batch_size, mdl.cells, self.C)]
+                        for wh, mdl in self.models.items()}
         self.objectives_dev = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.loss_ws = torch.zeros(ops.loss_ws_floats(batch_size, m.cells, self.A), dtype=torch.float32, device=dev)
+        self.loss_ws = torch.zeros(ops.loss_ws_floats(batch_size, m0.cells, self.A), dtype=torch.float32, device=dev)
+        for wh, (g, _) in traced.items():
+            if wh != largest:
+                e.add_size(g)
+        self.size = None
+        self.set_size(*own)
         self.hparam = [builder.hparam[k] for k in OBJECTIVE_KEYS]
         self.optimizer = Optimizer(optimizer, config if config is not None else builder.config, e.n_params, dev)
         self.lr_fn = learning_rate_fn(config if config is not None else builder.config, learning_rate)
@@ -49,6 +65,15 @@ class TrainSession(object):
         self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
+
+    def set_size(self, width, height):
+        """Input size of the following steps (one of the sizes the session was built with); weights, statistics, optimizer state
+        and global_step carry over.  Labels must be uploaded for the new grid."""
+        wh = (int(width), int(height))
+        self.engine.set_size(wh[1], wh[0])
+        self.model = self.models[wh]
+        self.labels = self._labels[wh]
+        self.size = wh
 
     def upload_labels(self, labels):
         for dst, src in zip(self.labels, labels):
