@@ -85,11 +85,15 @@ def main():
     builder(None)
     dtype = args.dtype or (config.get('mi355x', 'dtype') if config.has_option('mi355x', 'dtype') else 'bf16')
     sess = DetectSession(builder, 1, dtype=dtype)
-    model_path = checkpoint.latest_checkpoint(utils.get_logdir(config))
-    if model_path is None:
-        raise FileNotFoundError('no checkpoint in ' + utils.get_logdir(config))
-    logging.info('load ' + model_path)
-    logging.info('global_step=%d' % checkpoint.restore(model_path, engine=sess.engine))
+    from yolo_tf_amd import tf_checkpoint
+    logdir = utils.get_logdir(config)
+    model_path = checkpoint.latest_checkpoint(logdir)
+    tf_path = None if model_path else tf_checkpoint.latest_checkpoint(logdir)      # a logdir the reference trained (tf.train.latest_checkpoint, detect.py:104)
+    if model_path is None and tf_path is None:
+        raise FileNotFoundError('no checkpoint in ' + logdir)
+    logging.info('load ' + (model_path or tf_path))
+    step = checkpoint.restore(model_path, engine=sess.engine) if model_path else tf_checkpoint.restore(tf_path, engine=sess.engine)
+    logging.info('global_step=%d' % step)
     path = os.path.expanduser(os.path.expandvars(args.path))
     paths = [path] if os.path.isfile(path) else [os.path.join(d, f) for d, _, fs in os.walk(path) for f in fs
                                                  if os.path.splitext(f)[-1].lower() in args.exts]

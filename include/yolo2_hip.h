@@ -43,6 +43,9 @@ enum {
 
 int yolo2_abi_version(void);
 const char *yolo2_last_error(void);
+/* CRC32C (Castagnoli) of a HOST buffer, continuing from `crc` (0 to start): TFRecord / TensorBoard event / TF checkpoint files
+ * (the reference reads and writes them through TensorFlow: utils/data/cache.py:95-100, train.py:141-145, detect.py:104-106) */
+uint32_t yolo2_crc32c(const void *data, size_t n, uint32_t crc);
 /* releases the library-owned stream-K flag pools (after synchronising their devices); any later call re-creates them */
 int yolo2_shutdown(void);
 

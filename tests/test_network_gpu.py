@@ -630,3 +630,51 @@ def test_multi_scale_bf16_training_steps(basedir):
         assert np.isfinite(loss) and 0 < loss < 10, (size, loss)
     assert sess.global_step == 2 * len(sizes)
     assert torch.isfinite(sess.engine.params).all() and float((sess.engine.params - before).abs().max()) > 0
+
+
+def test_tensorflow_checkpoint_and_event_file_round_trip(basedir, tmp_path):
+    """a training session saved as a TensorFlow V2 checkpoint (the reference's tf.train.Saver layout: variables by TF
+    scope name, global_step, <var>/Adam and <var>/Adam_1 slots) restores into a fresh session bit for bit, continues identically,
+    and feeds a DetectSession; the summaries land in a TensorBoard event file."""
+    from yolo_tf_amd import tf_checkpoint
+    from yolo_tf_amd.session import DetectSession, TrainSession
+    from yolo_tf_amd.utils import data, events
+    os.environ['YOLO2_FUSE_BN_STATS'] = '0'              # two runs are compared bit for bit: order-independent statistics
+    try:
+        b, _ = make_builder('tiny', 20, 96, True, basedir)
+        images = torch.rand(2, 96, 96, 3, device='cuda', generator=torch.Generator(device='cuda').manual_seed(0)) * 255
+        labels = data.synthetic_batch(2, 20, 3, 3, seed=1)
+
+        def fresh():
+            return TrainSession(b, 2, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=9)
+        a = fresh()
+        writer = events.FileWriter(str(tmp_path / 'run'))
+        for _ in range(3):
+            a.step(images, labels)
+            writer.add_training_summary(a.global_step, a.fetch())
+        writer.close()
+        prefix = tf_checkpoint.save(str(tmp_path), a)
+        assert tf_checkpoint.latest_checkpoint(str(tmp_path)) == prefix and a.global_step == 3
+        names = set(tf_checkpoint.read_index(prefix)) - {''}
+        assert 'global_step' in names and 'yolo2_tiny/conv0/weights' in names and 'yolo2_tiny/conv0/weights/Adam_1' in names
+        c = fresh()
+        assert tf_checkpoint.restore(prefix, c) == 3
+        assert torch.equal(c.engine.params, a.engine.params) and torch.equal(c.engine.state, a.engine.state)
+        assert all(torch.equal(x, y) for x, y in zip(c.optimizer.slots, a.optimizer.slots))
+        a.step(images, labels)
+        c.step(images, labels)
+        torch.cuda.synchronize()
+        assert c.global_step == 4
+        # (filter gradients of split pixel ranges accumulate with f32 atomics: equal to rounding, not bitwise)
+        assert float((c.engine.params - a.engine.params).abs().max()) <= 1e-6
+        ev = events.read_events(writer.path)
+        assert [e['step'] for e in ev] == [0, 1, 2, 3] and [t for t, _ in ev[1]['scalars']] == list(events.SCALAR_TAGS)
+        bd, _ = make_builder('tiny', 20, 96, False, basedir)
+        det = DetectSession(bd, 1, dtype='f32')
+        assert tf_checkpoint.restore(prefix, engine=det.engine) == 3
+        got = det.engine.get_variables()
+        ref = a.engine.get_variables()
+        ref3 = tf_checkpoint.read(prefix)
+        assert all(np.array_equal(got[k], ref3[k]) for k in got) and set(got) <= set(ref)
+    finally:
+        del os.environ['YOLO2_FUSE_BN_STATS']

@@ -24,7 +24,8 @@ import time
 import numpy as np
 import torch
 
-from yolo_tf_amd import checkpoint, utils
+from yolo_tf_amd import checkpoint, tf_checkpoint, utils
+from yolo_tf_amd.utils import events
 from yolo_tf_amd.parallel import agree, init_distributed, sync_replicas
 from yolo_tf_amd.session import TrainSession
 from yolo_tf_amd.utils import data as udata
@@ -51,6 +52,7 @@ def make_args():
     parser.add_argument('--task', type=int, default=0, help='accepted for compatibility (rank comes from RANK)')
     parser.add_argument('--data', default='synthetic', help="'synthetic', 'cache' (the reference's TFRecord cache of -p profiles) or a .npz file")
     parser.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='overrides [mi355x] dtype')
+    parser.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help="checkpoint container: 'npz' (every optimizer) or 'tf' (TensorFlow V2 bundle, as the reference's tf.train.Saver writes)")
     return parser.parse_args()
 
 
@@ -131,13 +133,20 @@ def main():
     # rank 0 alone chooses and reads the checkpoint; the others receive parameters, statistics, optimizer slots and
     # global_step from it (same seed -> same initial weights anyway, but a restore must not depend on what each rank sees)
     latest = checkpoint.latest_checkpoint(logdir) if rank == 0 else None
+    latest_tf = tf_checkpoint.latest_checkpoint(logdir) if rank == 0 and not latest else None     # a logdir written by the reference (or --ckpt_format tf)
     if latest:
         step = checkpoint.restore(latest, session)
         logging.warning('resuming from %s (global_step=%d)' % (latest, step))
+    elif latest_tf:
+        step = tf_checkpoint.restore(latest_tf, session)
+        logging.warning('resuming from TensorFlow checkpoint %s (global_step=%d)' % (latest_tf, step))
     elif args.transfer and rank == 0:
         path = os.path.expanduser(os.path.expandvars(args.transfer))
         logging.warning('transferring from ' + path)
-        checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+        if os.path.exists(path + '.index'):                     # a TensorFlow checkpoint prefix, like the reference's -t argument
+            tf_checkpoint.restore(path, engine=session.engine, exclude=args.exclude)
+        else:
+            checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
     sync_replicas(session)
     logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
     if args.data == 'synthetic':
@@ -155,6 +164,9 @@ def main():
                                    config, seed, rank, world, session)
     else:
         data = NpzData(args.data, args.batch_size, seed, rank, world)
+    # the reference's summary_writer (train.py:141-145): scalar events under <logdir>/<logname>
+    writer = events.FileWriter(os.path.join(logdir, args.logname)) if rank == 0 else None
+    save = (lambda: tf_checkpoint.save(logdir, session)) if args.ckpt_format == 'tf' else (lambda: checkpoint.save(logdir, session))
     last_summary = last_save = t_rate = time.time()
     n_rate = 0
     sync_every = 1 if world == 1 else 20     # data parallel: decisions only one rank can make are agreed on every 20 steps
@@ -178,6 +190,8 @@ def main():
                 data.pipe.check()        # objects outside the grid / bad class ids / negative extents: the reference raises there
             rate = n_rate * args.batch_size * world / (time.time() - t_rate)
             if rank == 0:
+                writer.add_training_summary(session.global_step, s)
+                writer.flush()
                 logging.warning('step %d: total_loss=%.6f iou_best=%.6f iou_normal=%.6f coords=%.6f prob=%.6f (%.1f img/s)'
                                 % (session.global_step, s['total_loss'], s['iou_best'], s['iou_normal'], s['coords'], s['prob'], rate))
             (bad,) = agree([not np.isfinite(s['total_loss'])], device)
@@ -186,10 +200,11 @@ def main():
             last_summary, t_rate, n_rate = now, time.time(), 0
         if want_save:
             if rank == 0:
-                logging.warning('saved ' + checkpoint.save(logdir, session))
+                logging.warning('saved ' + save())
             last_save = now
     if rank == 0:
-        logging.warning('saved ' + checkpoint.save(logdir, session))
+        logging.warning('saved ' + save())
+        writer.close()
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

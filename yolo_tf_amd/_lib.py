@@ -75,6 +75,7 @@ QUERIES = {
     'yolo2_abi_version': (_i, []),
     'yolo2_last_error': (ctypes.c_char_p, []),
     'yolo2_shutdown': (_i, []),
+    'yolo2_crc32c': (ctypes.c_uint32, [_p, ctypes.c_size_t, ctypes.c_uint32]),
     'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
     'yolo2_debug_set_wgrad_variant': (None, [_i]),
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),

@@ -19,6 +19,37 @@ void yolo2_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 extern "C" const char *yolo2_last_error(void) { return g_err; }
+
+// CRC32C (Castagnoli) of a HOST buffer, slicing-by-8: the checksum of TFRecord / TensorBoard event / TF checkpoint files
+// (utils/tfrecord.py, utils/events.py, tf_checkpoint.py); `crc` = value so far (0 to start).  ~1.5 GB/s, against ~1 MB/s in Python.
+extern "C" uint32_t yolo2_crc32c(const void *data, size_t n, uint32_t crc) {
+    static uint32_t table[8][256];
+    static bool ready = [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            table[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = (table[t - 1][i] >> 8) ^ table[0][table[t - 1][i] & 0xFF];
+        return true;
+    }();
+    (void)ready;
+    const unsigned char *p = (const unsigned char *)data;
+    crc = ~crc;
+    while (n && ((uintptr_t)p & 7)) { crc = table[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8); --n; }
+    while (n >= 8) {
+        uint64_t w;
+        __builtin_memcpy(&w, p, 8);
+        w ^= crc;
+        crc = table[7][w & 0xFF] ^ table[6][(w >> 8) & 0xFF] ^ table[5][(w >> 16) & 0xFF] ^ table[4][(w >> 24) & 0xFF] ^
+              table[3][(w >> 32) & 0xFF] ^ table[2][(w >> 40) & 0xFF] ^ table[1][(w >> 48) & 0xFF] ^ table[0][(w >> 56) & 0xFF];
+        p += 8;
+        n -= 8;
+    }
+    while (n--) crc = table[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
 extern "C" int yolo2_abi_version(void) { return 1; }
 
 // ------------------------------------------------------------------------------------------

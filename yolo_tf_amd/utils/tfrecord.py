@@ -30,6 +30,17 @@ _TABLE = np.array(_TABLE, np.uint32)
 
 
 def crc32c(data):
+    """CRC32C of a bytes-like object: through the C-ABI library's yolo2_crc32c when it is built (checkpoints are hundreds of MB),
+    else the byte-at-a-time table below (records and events are small)."""
+    data = bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data
+    if len(data) >= 4096:
+        try:
+            from .. import _lib
+            import ctypes
+            buf = (ctypes.c_char * len(data)).from_buffer_copy(data) if not isinstance(data, bytes) else data
+            return int(_lib.load().yolo2_crc32c(buf, len(data), 0))
+        except Exception:
+            pass
     crc = 0xFFFFFFFF
     table = _TABLE
     for b in bytes(data):
