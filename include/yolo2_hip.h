@@ -243,6 +243,27 @@ int yolo2_loss(const void *logits, int ld, const float *anchors, const float *ma
                const float *areas, const float *hparam, float *objectives, void *dlogits,
                float *ws, int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream);
 
+/* ---- YOLO (v1) family, SURVEY 8f-4: model/yolo/__init__.py:37-100, model/yolo/inference.py:24-66 --------------------------
+ * Network output row per image [cells*C class scores | cells*boxes*(iou, x, y, sqrt_w, sqrt_h)], all linear; `ld` = row stride.
+ * yolo1_loss: Objectives + d(total weighted loss)/d(net) (label tensors and hparam order as yolo2_loss; prob is masked by the
+ * cell mask, cnt = B*cells*boxes); ws as yolo2_loss with A = boxes_per_cell.  yolo1_head_decode: the detection block (conf = iou *
+ * prob, corners in cell units). */
+int yolo1_loss(const void *net, int ld, const float *mask, const float *prob, const float *coords, const float *off_min,
+               const float *off_max, const float *areas, const float *hparam, float *objectives, void *dnet, float *ws,
+               int B, int cell_h, int cell_w, int boxes_per_cell, int C, int dtype, void *stream);
+int yolo1_head_decode(const void *net, int ld, float *conf, float *xy_min, float *xy_max, int *nan_flag, int B, int cell_h,
+                      int cell_w, int boxes_per_cell, int C, int dtype, void *stream);
+/* leaky_relu backward of an un-normalised layer, from its OUTPUT a: dZ = a >= 0 ? dA : alpha*dA (model/yolo/function.py:21-24;
+ * n elements, a multiple of 8 (bf16) / 4 (f32)) */
+int yolo2_leaky_bwd(const void *A, const void *dA, void *dZ, long n, float alpha, int dtype, void *stream);
+/* slim.layers.dropout in training (model/yolo/inference.py:57,60): Y = X * keep / keep_prob, keep ~ Bernoulli(keep_prob) from a
+ * counter-based hash of (seed, index); the byte mask is written for the backward pass.  seed == 0: `mask` is an input. */
+int yolo2_dropout(const void *X, void *Y, unsigned char *mask, long n, float keep_prob, unsigned long long seed, int dtype,
+                  void *stream);
+int yolo2_dropout_bwd(const void *dY, const unsigned char *mask, void *dX, long n, float keep_prob, int dtype, void *stream);
+/* slim.l2_regularizer(scale) on a weight tensor (model/yolo/inference.py:55): g += scale*w, *loss += scale*sum(w^2)/2 (device double) */
+int yolo2_l2_regularizer(const float *w, float *g, long n, float scale, double *loss, void *stream);
+
 /* ---- NMS: utils/postprocess.py:39-51 (iou :21-36), batched over images -----------------------
  * conf [B,N,C] f32 is updated in place exactly as the reference mutates it; order_out [B,N]
  * (int, may be NULL) receives per image the box indices in the order of the reference's

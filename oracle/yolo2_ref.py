@@ -868,3 +868,151 @@ def augment_image(src_u8, p, width, height):
     if p.get('gray'):
         img = rgb_to_grayscale3(img)
     return np.clip(img, 0, 255).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# YOLO (v1) family: model/yolo/inference.py:24-66 (tiny) and model/yolo/__init__.py:37-100.
+# [TF-sem] slim.layers.conv2d / fully_connected without a normalizer: weights (Xavier uniform) + biases (zeros) + activation;
+# slim.layers.flatten on NHWC = row-major (h, w, c); slim.layers.dropout(keep_prob) = x * mask / keep_prob;
+# slim.l2_regularizer(s)(w) = s * sum(w^2) / 2, added to tf.losses.get_total_loss.  PARITY UNPINNED (TensorFlow), as for yolo2.
+# ---------------------------------------------------------------------------------------------------------
+
+def yolo1_tiny_spec(classes, boxes_per_cell, cells):
+    ops = []
+    for i, (ch, pooled) in enumerate(((16, 1), (32, 1), (64, 1), (128, 1), (256, 1), (512, 1), (512, 0), (1024, 0), (256, 0))):
+        ops.append(('convb', 'conv%d' % i, 3, ch))
+        if pooled:
+            ops.append(('pool', 2))
+    ops.append(('flatten',))
+    for i, units in enumerate((256, 4096)):
+        ops += [('fc', 'fc%d' % i, units, True, 0.001), ('dropout', 'dropout%d' % i, 0.5)]
+    ops.append(('fc', 'fc', cells * (classes + boxes_per_cell * 5), False, 0.001))
+    return ops
+
+
+def yolo1_forward(spec, params, x, masks=None, quant=None):
+    """masks: {dropout name: 0/1 array} (training) or None (inference: dropout is the identity).  Returns (net [B, N], caches)."""
+    q = quant or _ident
+    net = q(x)
+    caches = []
+    for op in spec:
+        if op[0] == 'convb':
+            _, name, k, cout = op
+            out = q(leaky_relu(conv2d(net, q(params[name + '/weights'])) + params[name + '/biases']))
+            caches.append(('convb', name, net, out))
+            net = out
+        elif op[0] == 'pool':
+            caches.append(('pool', op[1], net))
+            net = max_pool(net, op[1])
+        elif op[0] == 'flatten':
+            caches.append(('flatten', net.shape))
+            net = net.reshape(net.shape[0], -1)
+        elif op[0] == 'fc':
+            _, name, cout, act, l2 = op
+            z = net @ q(params[name + '/weights']) + params[name + '/biases']
+            out = q(leaky_relu(z) if act else z)
+            caches.append(('fc', name, net, out))
+            net = out
+        elif op[0] == 'dropout':
+            if masks is not None:
+                m = masks[op[1]].reshape(net.shape).astype(net.dtype)
+                caches.append(('dropout', m, op[2]))
+                net = q(net * m / net.dtype.type(op[2]))
+            else:
+                caches.append(('dropout', None, op[2]))
+    return net, caches
+
+
+def yolo1_backward(spec, params, caches, dnet, quant=None):
+    q = quant or _ident
+    grads = {}
+    reg = 0.0
+    dnet = q(dnet)
+    for op, cache in zip(reversed(spec), reversed(caches)):
+        if op[0] == 'fc':
+            _, name, cout, act, l2 = op
+            _, _, xin, out = cache
+            dz = q(leaky_relu_grad(out, dnet)) if act else dnet
+            w = params[name + '/weights']
+            grads[name + '/weights'] = xin.T @ dz + w.dtype.type(l2) * w
+            grads[name + '/biases'] = dz.astype(np.float64).sum(0).astype(dz.dtype)
+            reg += l2 * float((w.astype(np.float64) ** 2).sum()) / 2
+            dnet = q(dz @ q(w).T)
+        elif op[0] == 'dropout':
+            if cache[1] is not None:
+                dnet = q(dnet * cache[1] / dnet.dtype.type(cache[2]))
+        elif op[0] == 'flatten':
+            dnet = dnet.reshape(cache[1])
+        elif op[0] == 'pool':
+            dnet = max_pool_grad(cache[2], dnet, cache[1])
+        elif op[0] == 'convb':
+            _, name, k, cout = op
+            _, _, xin, out = cache
+            dz = q(leaky_relu_grad(out, dnet))             # sign(out) == sign(z) for alpha > 0
+            grads[name + '/weights'] = conv2d_wgrad(xin, dz, k, k)
+            grads[name + '/biases'] = dz.reshape(-1, cout).astype(np.float64).sum(0).astype(dz.dtype)
+            dnet = q(conv2d_dgrad(dz, q(params[name + '/weights'])))
+    return grads, reg
+
+
+def yolo1_model_decode(net, classes, boxes_per_cell, cell_height, cell_width, training=False):
+    """model/yolo/__init__.py:37-66."""
+    t = net.dtype.type
+    b = net.shape[0]
+    cells = cell_height * cell_width
+    end = cells * classes
+    m = {'cell_width': cell_width, 'cell_height': cell_height}
+    m['prob'] = net[:, :end].reshape(b, cells, 1, classes)                                    # :43
+    rem = net[:, end:end + cells * boxes_per_cell * 5].reshape(b, cells, boxes_per_cell, 5)   # :44
+    m['iou'] = rem[..., 0]
+    m['offset_xy'] = rem[..., 1:3]
+    base = rem[..., 3:]
+    m['wh01_sqrt_base'] = base
+    wh01 = base * base                                                                        # :48
+    m['coords'] = np.concatenate([m['offset_xy'], np.abs(base)], -1)                          # :49-50
+    m['wh'] = wh01 * np.array([cell_width, cell_height], net.dtype)                           # :51
+    half = m['wh'] / t(2)
+    m['offset_xy_min'] = m['offset_xy'] - half
+    m['offset_xy_max'] = m['offset_xy'] + half
+    m['areas'] = m['wh'][..., 0] * m['wh'][..., 1]
+    if not training:
+        cell_xy = calc_cell_xy(cell_height, cell_width, net.dtype).reshape(1, cells, 1, 2)
+        m['xy'] = cell_xy + m['offset_xy']
+        m['xy_min'] = cell_xy + m['offset_xy_min']
+        m['xy_max'] = cell_xy + m['offset_xy_max']
+        m['conf'] = m['iou'][..., None] * m['prob']
+    return m
+
+
+def yolo1_objectives(m, labels):
+    """model/yolo/__init__.py:69-100: as yolo2's, except that the class term is per cell and masked by `mask` (:100)."""
+    mask, prob, coords, oxy_min, oxy_max, areas = labels
+    t = m['iou'].dtype.type
+    _wh = np.maximum(np.minimum(m['offset_xy_max'], oxy_max) - np.maximum(m['offset_xy_min'], oxy_min), t(0))
+    _areas = _wh[..., 0] * _wh[..., 1]
+    iou = _areas / np.maximum(areas + m['areas'] - _areas, t(1e-10))
+    mask_best = mask * (iou == iou.max(2, keepdims=True)).astype(iou.dtype)
+    iou_dist = (m['iou'] - mask_best) ** 2
+    coords_dist = (m['coords'] - coords) ** 2
+    prob_dist = (m['prob'] - prob) ** 2
+    cnt = t(iou_dist.size)
+    obj = {'iou_best': (mask_best * iou_dist).sum(dtype=np.float64) / cnt, 'iou_normal': ((t(1) - mask_best) * iou_dist).sum(dtype=np.float64) / cnt,
+           'coords': (mask_best[..., None] * coords_dist).sum(dtype=np.float64) / cnt, 'prob': (mask[..., None] * prob_dist).sum(dtype=np.float64) / cnt}
+    return {k: t(v) for k, v in obj.items()}, {'mask_best': mask_best, 'cnt': cnt}
+
+
+def yolo1_loss_backward(m, labels, aux, hparam, classes, boxes_per_cell, width):
+    """d(sum of weighted objectives)/d(net); every output is linear, |x| differentiates to sign(x)."""
+    mask, prob_t, coords_t, _, _, _ = labels
+    t = m['iou'].dtype.type
+    mb, cnt, two = aux['mask_best'], aux['cnt'], t(2)
+    b, cells, _ = m['iou'].shape
+    d = np.zeros((b, width), m['iou'].dtype)
+    d[:, :cells * classes] = (two * mask[..., None] * (m['prob'] - prob_t) * t(hparam['prob']) / cnt).reshape(b, -1)
+    r = np.zeros((b, cells, boxes_per_cell, 5), m['iou'].dtype)
+    r[..., 0] = two * (m['iou'] - mb) * (t(hparam['iou_best']) * mb + t(hparam['iou_normal']) * (t(1) - mb)) / cnt
+    r[..., 1:3] = two * mb[..., None] * (m['offset_xy'] - coords_t[..., :2]) * t(hparam['coords']) / cnt
+    base = m['wh01_sqrt_base']
+    r[..., 3:5] = two * mb[..., None] * (np.abs(base) - coords_t[..., 2:4]) * t(hparam['coords']) / cnt * np.sign(base)
+    d[:, cells * classes:cells * (classes + boxes_per_cell * 5)] = r.reshape(b, -1)
+    return d

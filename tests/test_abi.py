@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     text = open(os.path.join(ROOT, 'include', 'yolo2_hip.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(yolo2_[a-z0-9_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(yolo[12]_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_library_exports_every_declared_symbol():

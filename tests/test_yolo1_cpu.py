@@ -1,0 +1,104 @@
+"""YOLO (v1) family on the CPU: the traced `tiny` graph (reference model/yolo/inference.py:24-66) and the oracle's v1 restatement
+against torch fp64 autograd (an independent differentiation of the same formulas)."""
+import os
+import tempfile
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import yolo2_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = {'prob': 1., 'iou_best': 1., 'iou_normal': .5, 'coords': 5.}
+
+
+def test_tiny_graph_matches_reference_topology():
+    from yolo_tf_amd import utils
+    from yolo_tf_amd.model import yolo
+    with tempfile.TemporaryDirectory() as d:
+        cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo', 'tiny-20.ini')], d)
+        cfg.set('cache', 'names', os.path.join(ROOT, cfg.get('cache', 'names')))
+        utils.ensure_names(cfg)
+        b = yolo.Builder(None, cfg)
+        b(None, training=True)
+        b.create_objectives()
+    assert yolo.inference.TINY_DOWNSAMPLING == (64, 64) and (b.width, b.height) == (448, 448)
+    m = b.model
+    assert (m.cell_width, m.cell_height, m.cells, m.boxes_per_cell, m.classes) == (7, 7, 49, 2, 20)
+    kinds = [op['kind'] for op in b.graph.ops]
+    assert kinds.count('conv') == 12 and kinds.count('pool') == 6 and kinds.count('dropout') == 2 and kinds.count('flatten') == 1
+    out = b.graph.ops[-1]['out']
+    assert out.c == 49 * (20 + 2 * 5) == 1470
+    assert sum(int(np.prod(v.shape)) for v in b.graph.variables.values() if v.trainable) == 21298526
+    names = list(b.graph.variables)
+    assert 'yolo_tiny/conv0/weights' in names and 'yolo_tiny/fc1/biases' in names and 'yolo_tiny/fc/weights' in names
+    assert b.hparam == HP
+
+
+def test_yolo1_oracle_matches_torch_autograd():
+    rng = np.random.RandomState(0)
+    B, classes, boxes, size, cells = 2, 3, 2, 128, 4
+    spec = R.yolo1_tiny_spec(classes, boxes, cells)
+    params, c, hw = {}, 3, size
+    for op in spec:
+        if op[0] == 'convb':
+            params[op[1] + '/weights'] = rng.randn(3, 3, c, op[3]) / np.sqrt(9 * c)
+            params[op[1] + '/biases'] = rng.randn(op[3]) * 0.1
+            c = op[3]
+        elif op[0] == 'pool':
+            hw //= 2
+        elif op[0] == 'flatten':
+            c = hw * hw * c
+        elif op[0] == 'fc':
+            params[op[1] + '/weights'] = rng.randn(c, op[2]) / np.sqrt(c)
+            params[op[1] + '/biases'] = rng.randn(op[2]) * 0.1
+            c = op[2]
+    x = rng.randn(B, size, size, 3)
+    masks = {'dropout0': (rng.rand(B, 256) < 0.5).astype(np.uint8), 'dropout1': (rng.rand(B, 4096) < 0.5).astype(np.uint8)}
+    from yolo_tf_amd.utils import data
+    labels = [l.astype(np.float64) for l in data.synthetic_batch(B, classes, 2, 2, seed=1)]
+    net, caches = R.yolo1_forward(spec, params, x, masks)
+    m = R.yolo1_model_decode(net, classes, boxes, 2, 2, training=True)
+    obj, aux = R.yolo1_objectives(m, labels)
+    dnet = R.yolo1_loss_backward(m, labels, aux, HP, classes, boxes, net.shape[1])
+    g, reg = R.yolo1_backward(spec, params, caches, dnet)
+
+    tp = {k: torch.tensor(v, requires_grad=True) for k, v in params.items()}
+    t = torch.tensor(x).permute(0, 3, 1, 2)
+    for op in spec:
+        if op[0] == 'convb':
+            t = F.conv2d(t, tp[op[1] + '/weights'].permute(3, 2, 0, 1), tp[op[1] + '/biases'], 1, 1)
+            t = torch.maximum(t, 0.1 * t)
+        elif op[0] == 'pool':
+            t = F.max_pool2d(t, 2, 2)
+        elif op[0] == 'flatten':
+            t = t.permute(0, 2, 3, 1).reshape(B, -1)
+        elif op[0] == 'fc':
+            t = t @ tp[op[1] + '/weights'] + tp[op[1] + '/biases']
+            if op[3]:
+                t = torch.maximum(t, 0.1 * t)
+        elif op[0] == 'dropout':
+            t = t * torch.tensor(masks[op[1]].astype(np.float64)) / op[2]
+    assert np.allclose(t.detach().numpy(), net, atol=1e-10)
+    prob = t[:, :cells * classes].reshape(B, cells, 1, classes)
+    rem = t[:, cells * classes:].reshape(B, cells, boxes, 5)
+    iou_p, oxy, base = rem[..., 0], rem[..., 1:3], rem[..., 3:]
+    wh = base * base * torch.tensor([2., 2.], dtype=torch.float64)
+    coords = torch.cat([oxy, base.abs()], -1)
+    mn, mx, areas = oxy - wh / 2, oxy + wh / 2, wh[..., 0] * wh[..., 1]
+    mask, tprob, tcoords, tmn, tmx, tareas = [torch.tensor(l) for l in labels]
+    iw = torch.clamp(torch.minimum(mx, tmx) - torch.maximum(mn, tmn), min=0)
+    inter = iw[..., 0] * iw[..., 1]
+    iou = inter / torch.clamp(tareas + areas - inter, min=1e-10)
+    mb = (mask * (iou == iou.max(2, keepdim=True).values).double()).detach()
+    cnt = float(iou.numel())
+    terms = {'iou_best': (mb * (iou_p - mb) ** 2).sum() / cnt, 'iou_normal': ((1 - mb) * (iou_p - mb) ** 2).sum() / cnt,
+             'coords': (mb[..., None] * (coords - tcoords) ** 2).sum() / cnt, 'prob': (mask[..., None] * (prob - tprob) ** 2).sum() / cnt}
+    for k in terms:
+        assert abs(float(terms[k].detach()) - float(obj[k])) <= 1e-12 * max(1.0, abs(float(obj[k]))), k
+    regt = sum(0.001 * (tp[op[1] + '/weights'] ** 2).sum() / 2 for op in spec if op[0] == 'fc')
+    (sum(HP[k] * terms[k] for k in terms) + regt).backward()
+    for k in g:
+        assert np.allclose(tp[k].grad.numpy(), g[k], rtol=1e-8, atol=1e-12), k
+    assert abs(float(regt.detach()) - reg) < 1e-12

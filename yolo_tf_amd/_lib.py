@@ -55,6 +55,12 @@ SIGNATURES = {
     'yolo2_head_decode': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_head_decode_attrs': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo1_loss': [_p, _i, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo1_head_decode': [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_leaky_bwd': [_p, _p, _p, _l, _f, _i, _p],
+    'yolo2_dropout': [_p, _p, _p, _l, _f, ctypes.c_ulonglong, _i, _p],
+    'yolo2_dropout_bwd': [_p, _p, _p, _l, _f, _i, _p],
+    'yolo2_l2_regularizer': [_p, _p, _l, _f, _p, _p],
     'yolo2_nms': [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _p],
     'yolo2_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p],
     'yolo2_momentum': [_p, _p, _p, _l, _f, _f, _f, _p],

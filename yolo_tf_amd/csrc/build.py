@@ -14,6 +14,7 @@ SOURCES = {
     'conv_first.hip': [],
     'elementwise.hip': [],
     'head.hip': ['-ffp-contract=off'],
+    'yolo1.hip': ['-ffp-contract=off'],
     'nms.hip': ['-ffp-contract=off'],
     'augment.hip': ['-ffp-contract=off'],
 }

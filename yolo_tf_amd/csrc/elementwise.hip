@@ -457,11 +457,27 @@ static int bn_stats_impl(const void *Y, float *mean, float *var, float *mm, floa
     return YOLO2_OK;
 }
 
+// wide rows (the fully connected layers of the YOLO v1 family: M = batch, thousands of columns): one lane per column, rows in order
+template <typename T>
+__global__ void colsum_wide_kernel(const T *__restrict__ dY, int ld, long M, int C, float *__restrict__ dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (long r = 0; r < M; ++r) acc += (double)(float)dY[r * ld + c];
+    dbias[c] = (float)acc;
+}
+
 extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, int C, int dtype, void *stream) {
     Y2_CHECK_ARG(dY && dbias && ws && M > 0 && C > 0 && ld >= C);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
-    Y2_CHECK_ARG(ld % vec == 0 && ld / vec <= 256);
     hipStream_t st = (hipStream_t)stream;
+    if (ld / vec > 256) {
+        Y2_CHECK_ARG(M <= 4096);
+        Y2_DISPATCH_DTYPE(dtype, colsum_wide_kernel<T><<<cdiv(C, 256), 256, 0, st>>>((const T *)dY, ld, M, C, dbias));
+        Y2_CHECK_LAUNCH();
+        return YOLO2_OK;
+    }
+    Y2_CHECK_ARG(ld % vec == 0);
     // reduce over the padded width ld (padding lanes are zero by contract), report the first C
     const int nb = colsum_grid(M, ld, vec);
     float *part = (float *)ws;

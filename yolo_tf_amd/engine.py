@@ -64,6 +64,11 @@ class Engine(object):
         self.init_variables(seed)
         self._filters_dirty = True
         self._zero_ranges = None
+        self.reg_loss = torch.zeros(1, dtype=torch.float64, device=self.device)      # sum of the regularisation terms of the last backward
+        self.dropout_masks = None    # {op name: uint8 mask}: fixed keep masks (parity tests); None = drawn on the device per step
+        self.dropout_seed = int(seed) + 1
+        self._dropout_calls = 0
+        self._masks = {}
         self._phase = 'fwd'          # 'fwd' | 'dgrad': which sweep a conv launch belongs to (timer tag)
         self.kernel_timer = None     # optional bench.KernelTimer: HIP events around the dominant conv kernel
 
@@ -367,9 +372,22 @@ class Engine(object):
                     else:
                         ob, ldo = self.act[out]
                         ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
+                elif op['act']:
+                    # un-normalised layer of the YOLO (v1) family: conv / fully connected + biases + leaky_relu in one launch
+                    ob, ldo = self.act[out]
+                    ops.conv2d_bias_leaky(xb, st['Ffwd'], self.var[op['biases'].name], ob, self.conv_ws, B, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], LEAKY_ALPHA)
                 else:
                     ob, ldo = self.act[out]
                     self._conv(xb, st['Ffwd'], self.var[op['biases'].name], ob, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], op['ksize'] ** 2 * op['cin'])
+            elif kind == 'flatten':
+                pass                         # the same bytes, re-read as one pixel
+            elif kind == 'dropout':
+                x, out = op['x'], op['out']
+                n = B * x.h * x.w * self.act[x][1]
+                mask = self._dropout_mask(op, n)
+                fixed = self.dropout_masks is not None
+                self._dropout_calls += 1
+                ops.dropout(self.act[x][0], self.act[out][0], mask, n, op['keep_prob'], 0 if fixed else self.dropout_seed * 1000003 + self._dropout_calls)
             elif kind == 'pool':
                 x, out = op['x'], op['out']
                 if x in self.fused_pool:
@@ -413,6 +431,7 @@ class Engine(object):
         written = set()
         inputs = set(self.graph.inputs.values())
         self._phase = 'dgrad'
+        self.reg_loss.zero_()
         main = torch.cuda.current_stream()
         side = self.side_stream if self.overlap_wgrad else None
         slot = 0
@@ -447,6 +466,16 @@ class Engine(object):
                     else:
                         ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy, M, cout, BN_EPS, LEAKY_ALPHA)
                     ring = True
+                elif op['act']:
+                    # un-normalised layer + leaky_relu (YOLO v1): dZ from the layer's output sign, then the biased-layer path
+                    assert ldgo == ldy and self.act[out][1] == ldy
+                    slot = (slot + 1) % 3
+                    dy = self.dy_ring[slot]
+                    if self.dy_free[slot] is not None:
+                        main.wait_event(self.dy_free[slot])
+                    ops.leaky_bwd(self.act[out][0], gob, dy, M * ldy, LEAKY_ALPHA)
+                    ops.bias_grad(dy, ldy, self.gvar[op['biases'].name], self.ws, M, cout)
+                    ring = True
                 else:
                     dy = gob
                     assert ldgo == ldy
@@ -459,12 +488,14 @@ class Engine(object):
                     side.wait_event(ready)
                     with torch.cuda.stream(side):
                         ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
+                        self._l2(op)
                         done = torch.cuda.Event()
                         done.record(side)
                     if ring:
                         self.dy_free[slot] = done
                 else:
                     ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
+                    self._l2(op)
                 if x not in inputs:
                     dst, ldd, fin = self._grad_sink(x, written)
                     self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
@@ -491,9 +522,33 @@ class Engine(object):
             elif kind == 'concat':
                 for v in op['inputs']:
                     written.add(v)           # their gradients are slices of the concat gradient
+            elif kind == 'flatten':
+                written.add(op['x'])         # the gradient of the flat view IS the gradient of the tensor
+            elif kind == 'dropout':
+                x, out = op['x'], op['out']
+                dst, ldd, fin = self._grad_sink(x, written)
+                n = B * x.h * x.w * ldd
+                ops.dropout_bwd(self.gact[out][0], self._dropout_mask(op, n), dst, n, op['keep_prob'])
+                if fin:
+                    fin()
         self._phase = 'fwd'
         if side is not None:
             main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
+
+    def _l2(self, op):
+        """slim.l2_regularizer on a layer's weights (YOLO v1 fully connected layers): gradient and loss term, on the stream of the
+        filter gradient it follows."""
+        if op.get('l2', 0.0) > 0.0:
+            w = self.var[op['weights'].name]
+            ops.l2_regularizer(w, self.gvar[op['weights'].name], w.numel(), op['l2'], self.reg_loss)
+
+    def _dropout_mask(self, op, n):
+        if self.dropout_masks is not None:
+            return self.dropout_masks[op['name']]
+        m = self._masks.get(op['name'])
+        if m is None or m.numel() < n:
+            m = self._masks[op['name']] = torch.zeros(n, dtype=torch.uint8, device=self.device)
+        return m
 
     def output(self):
         return self.graph.ops[-1]['out']

@@ -26,6 +26,7 @@ class Tensor(object):
         self.h, self.w, self.c = h, w, c
         self.ld = ld if ld is not None else pad8(c)
         self.base = None          # (Tensor, channel offset) when this tensor lives inside a concat buffer
+        self.flat_of = None       # Tensor whose [h, w, c] pixels this [1, 1, h*w*c] tensor re-reads (slim.layers.flatten)
         self.producer = None
         self.n_consumers = 0
 
@@ -34,6 +35,10 @@ class Tensor(object):
 
     def storage(self):
         """Resolves aliases: returns (root tensor, channel offset, ld)."""
+        if self.flat_of is not None:
+            r, off, _ = self.flat_of.storage()
+            assert off == 0
+            return r, 0, self.ld
         t, off = self, 0
         while t.base is not None:
             off += t.base[1]
@@ -110,6 +115,12 @@ def truncated_normal(stddev):
     return init
 
 
+def xavier_uniform_fc(rng, shape):
+    """[TF-sem] slim.fully_connected default initialiser: Xavier uniform over (fan_in, fan_out)."""
+    lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
 def zeros(rng, shape):
     return np.zeros(shape, np.float32)
 
@@ -145,11 +156,49 @@ def conv2d(net, num_outputs, kernel_size=3, scope=None, batch_norm=True, activat
         op['y'] = g.tensor(scope + '/convolution', net.h, net.w, num_outputs)
         assert activation, 'normalised convolutions are always followed by leaky_relu on this path'
     else:
-        assert not activation
+        # no normaliser: slim adds `biases` (zeros) and applies the activation, if any, after the bias add -- the YOLOv1 stack
+        # (reference model/yolo/inference.py:27-50) and the biased final 1x1 of YOLOv2
         op['biases'] = g.variable(scope + '/biases', (num_outputs,), zeros)
     op['out'] = g.tensor(scope + ('/leaky_relu' if activation else '/BiasAdd'), net.h, net.w, num_outputs)
     g.add(op)
     return op['out']
+
+
+def flatten(net, scope=None):
+    """slim.layers.flatten on NHWC: [B, h, w, c] -> [B, h*w*c] in (h, w, c) order (reference model/yolo/inference.py:54) -- the same
+    bytes, re-read as one pixel of h*w*c channels (needs an unpadded pixel stride)."""
+    assert net.base is None and net.ld == net.c, 'flatten needs a dense tensor'
+    g = net.graph
+    out = g.tensor(scope or (net.name + '/flatten'), 1, 1, net.h * net.w * net.c, ld=net.h * net.w * net.c)
+    out.flat_of = net
+    g.add({'kind': 'flatten', 'name': out.name, 'inputs': [net], 'x': net, 'out': out})
+    return out
+
+
+def fully_connected(net, num_outputs, scope=None, activation=True, weights_regularizer=0.0, weights_initializer=xavier_uniform_fc):
+    """slim.layers.fully_connected (reference model/yolo/inference.py:55-61): weights [in, out] + biases, optional leaky_relu,
+    optional slim.l2_regularizer(scale) on the weights.  Executed as a 1x1 convolution over the one-pixel image."""
+    assert net.h == 1 and net.w == 1
+    g = net.graph
+    num_outputs = int(num_outputs)
+    w = g.variable(scope + '/weights', (net.c, num_outputs), weights_initializer)
+    op = {'kind': 'conv', 'name': scope, 'inputs': [net], 'x': net, 'ksize': 1, 'cin': net.c, 'cout': num_outputs, 'bn': False,
+          'act': bool(activation), 'weights': w, 'l2': float(weights_regularizer), 'fc': True}
+    op['biases'] = g.variable(scope + '/biases', (num_outputs,), zeros)
+    op['out'] = g.tensor(scope + ('/leaky_relu' if activation else '/BiasAdd'), 1, 1, num_outputs)
+    g.add(op)
+    return op['out']
+
+
+def dropout(net, keep_prob=0.5, is_training=False, scope=None):
+    """slim.layers.dropout (reference model/yolo/inference.py:57,60): identity at inference; in training x * mask / keep_prob with
+    mask ~ Bernoulli(keep_prob) drawn on the device per step."""
+    if not is_training:
+        return net
+    g = net.graph
+    out = g.tensor(scope, net.h, net.w, net.c)
+    g.add({'kind': 'dropout', 'name': scope, 'inputs': [net], 'x': net, 'out': out, 'keep_prob': float(keep_prob)})
+    return out
 
 
 def max_pool2d(net, stride=2, scope=None):

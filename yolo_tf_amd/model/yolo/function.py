@@ -1,10 +1,15 @@
-"""leaky_relu (reference model/yolo/function.py:21-24): max(x, 0.1*x).  On the MI355X path the
-activation is never a standalone op: it is fused into the batch-norm apply kernel
-(csrc/elementwise.hip bn_leaky_kernel) and its gradient into the BN backward kernels, so this
-module only carries the constant the kernels are launched with."""
+"""model/yolo/function.py of the reference: ``leaky_relu(inputs, alpha=.1) = max(inputs, alpha * inputs)`` (:21-24).
+
+On this path the activation never runs on its own: it is the epilogue of the convolution / fully connected kernel
+(``yolo2_conv2d_bias_leaky``) or of the batch-norm kernels, and its gradient is ``yolo2_leaky_bwd`` / the BN backward kernels.
+The symbol is kept because the inference plugins name it as their ``activation_fn``."""
+
 ALPHA = 0.1
 
 
 def leaky_relu(inputs, alpha=ALPHA):
-    raise NotImplementedError('leaky_relu is fused into graph.conv2d(..., activation=True); '
-                              'it does not exist as a separate op on this path')
+    """Marks a layer's activation (the graph layer functions take ``activation=True``); on a NumPy array it evaluates the
+    reference formula, which is what host-side callers (tests, tools) get."""
+    import numpy as np
+    a = np.asarray(inputs)
+    return np.maximum(a, a.dtype.type(alpha) * a)

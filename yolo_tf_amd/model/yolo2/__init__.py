@@ -74,6 +74,8 @@ class Objectives(dict):
 
 
 class Builder(yolo.Builder):
+    family = 'yolo2'
+
     def __init__(self, args, config):
         section = __name__.split('.')[-1]                    # 'yolo2'
         self.args = args                                      # stored, never read (as in the reference)

@@ -244,3 +244,31 @@ def transform_labels(objects_class, objects_coord, first_object, mask, prob, coo
                      cell_width, cell_height, error_flag):
     call('yolo2_transform_labels', ptr(objects_class), ptr(objects_coord), ptr(first_object), ptr(mask), ptr(prob), ptr(coords),
          ptr(offset_xy_min), ptr(offset_xy_max), ptr(areas), B, classes, cell_width, cell_height, ptr(error_flag), _stream())
+
+
+# ---- YOLO (v1) family
+def yolo1_loss(net, ld, labels, hparam, objectives, dnet, ws, B, ch, cw, boxes, C):
+    hp = (ctypes.c_float * 4)(*[float(v) for v in hparam])
+    mask, prob, coords, omin, omax, areas = labels
+    call('yolo1_loss', ptr(net), ld, ptr(mask), ptr(prob), ptr(coords), ptr(omin), ptr(omax), ptr(areas), hp, ptr(objectives), ptr(dnet), ptr(ws),
+         B, ch, cw, boxes, C, dtype_code(net.dtype), _stream())
+
+
+def yolo1_head_decode(net, ld, conf, xy_min, xy_max, nan_flag, B, ch, cw, boxes, C):
+    call('yolo1_head_decode', ptr(net), ld, ptr(conf), ptr(xy_min), ptr(xy_max), ptr(nan_flag), B, ch, cw, boxes, C, dtype_code(net.dtype), _stream())
+
+
+def leaky_bwd(A, dA, dZ, n, alpha):
+    call('yolo2_leaky_bwd', ptr(A), ptr(dA), ptr(dZ), n, alpha, dtype_code(A.dtype), _stream())
+
+
+def dropout(X, Y, mask, n, keep_prob, seed):
+    call('yolo2_dropout', ptr(X), ptr(Y), ptr(mask), n, keep_prob, int(seed), dtype_code(X.dtype), _stream())
+
+
+def dropout_bwd(dY, mask, dX, n, keep_prob):
+    call('yolo2_dropout_bwd', ptr(dY), ptr(mask), ptr(dX), n, keep_prob, dtype_code(dY.dtype), _stream())
+
+
+def l2_regularizer(w, g, n, scale, loss):
+    call('yolo2_l2_regularizer', ptr(w), ptr(g), n, scale, ptr(loss), _stream())

@@ -31,6 +31,8 @@ class TrainSession(object):
         self.B = batch_size
         own = (builder.width, builder.height)
         traced = {own: (builder.graph, builder.model)}
+        self.v1 = getattr(builder, 'family', 'yolo2') == 'yolo'       # YOLO (v1): linear fully connected head, boxes_per_cell instead of anchors
+        assert not (self.v1 and sizes), 'the fully connected YOLO (v1) head fixes the input size'
         for wh in (sizes or []):
             wh = (int(wh[0]), int(wh[1]))
             if wh not in traced:
@@ -41,9 +43,9 @@ class TrainSession(object):
         e = self.engine
         self.models = {wh: gm[1] for wh, gm in traced.items()}
         m0 = traced[largest][1]
-        self.A, self.C = len(m0.anchors), m0.classes
+        self.A, self.C = (m0.boxes_per_cell if self.v1 else len(m0.anchors)), m0.classes
         dev = e.device
-        self.anchors = torch.from_numpy(m0.anchors.reshape(-1)).to(dev)
+        self.anchors = None if self.v1 else torch.from_numpy(m0.anchors.reshape(-1)).to(dev)
         self._labels = {wh: [torch.zeros(*s, dtype=torch.float32, device=dev) for s in _label_shapes(batch_size, mdl.cells, self.C)]
                         for wh, mdl in self.models.items()}
         self.objectives_dev = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -89,8 +91,11 @@ class TrainSession(object):
         out = e.output()
         logits, ld = e.act[out]
         dlogits, _ = e.gact[out]
-        ops.loss(logits, ld, self.anchors, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws,
-                 self.B, m.cell_height, m.cell_width, self.A, self.C)
+        if self.v1:
+            ops.yolo1_loss(logits, ld, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws, self.B, m.cell_height, m.cell_width, self.A, self.C)
+        else:
+            ops.loss(logits, ld, self.anchors, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws,
+                     self.B, m.cell_height, m.cell_width, self.A, self.C)
         if self.reducer is not None:
             self.reducer.begin()
             e.backward(on_layer_done=lambda op, ev: self.reducer.ready_upto(self._layer_end[op['name']], ev))
@@ -133,7 +138,8 @@ class TrainSession(object):
         (the five scalars the reference summarises, config.ini:63)."""
         vals = self.objectives_dev.cpu().numpy().astype(np.float64)
         out = {k: float(v) for k, v in zip(OBJECTIVE_KEYS, vals)}
-        out['total_loss'] = float(sum(v * w for v, w in zip(vals, self.hparam)))
+        out['regularization'] = float(self.engine.reg_loss.item())        # slim.l2_regularizer terms (YOLO v1 fully connected layers; 0 for yolo2)
+        out['total_loss'] = float(sum(v * w for v, w in zip(vals, self.hparam))) + out['regularization']
         self.builder.objectives.update({k: out[k] for k in OBJECTIVE_KEYS})
         return out
 
@@ -147,10 +153,11 @@ class DetectSession(object):
         self.model = m = builder.model
         self.engine = Engine(builder.graph, batch_size, dtype, training=False, seed=seed)
         dev = self.engine.device
-        self.B, self.A, self.C = batch_size, len(m.anchors), m.classes
+        self.v1 = getattr(builder, 'family', 'yolo2') == 'yolo'
+        self.B, self.A, self.C = batch_size, (m.boxes_per_cell if self.v1 else len(m.anchors)), m.classes
         n = m.cells * self.A
         self.N = n
-        self.anchors = torch.from_numpy(m.anchors.reshape(-1)).to(dev)
+        self.anchors = None if self.v1 else torch.from_numpy(m.anchors.reshape(-1)).to(dev)
         self.conf = torch.zeros(batch_size, n, self.C, dtype=torch.float32, device=dev)
         self.xy_min = torch.zeros(batch_size, n, 2, dtype=torch.float32, device=dev)
         self.xy_max = torch.zeros(batch_size, n, 2, dtype=torch.float32, device=dev)
@@ -169,8 +176,11 @@ class DetectSession(object):
         logits, ld = e.act[e.output()]
         self._attrs_valid = False
         self.nan_flag.zero_()
-        ops.head_decode(logits, ld, self.anchors, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height,
-                        m.cell_width, self.A, self.C)
+        if self.v1:
+            ops.yolo1_head_decode(logits, ld, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height, m.cell_width, self.A, self.C)
+        else:
+            ops.head_decode(logits, ld, self.anchors, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height,
+                            m.cell_width, self.A, self.C)
         if check_numerics and int(self.nan_flag.item()) != 0:
             raise FloatingPointError('conf/xy_min/xy_max : Tensor had NaN or Inf values')
         return self.conf, self.xy_min, self.xy_max
