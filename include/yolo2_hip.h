@@ -127,6 +127,23 @@ int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int to
 int yolo2_conv2d_bias_leaky(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B,
                             int H, int W, int Cp, int ldp, int Nf, int ldo, int ksize, float alpha, int dtype, void *stream);
 
+/* Data-gradient convolution whose output dX is the gradient of a batch-normalised producer layer's activation
+ * (a = leaky_relu(batch_norm(y)), model/yolo2/inference.py:62-66): as yolo2_conv2d_ws(dY, F, NULL, dX, ...) FOLLOWED BY
+ * yolo2_bn_leaky_bwd_reduce(dX, ldo, Yprev, mean, var, gamma, beta, dgamma, dbeta, ...) -- the gradients of slim.batch_norm's
+ * gamma/beta that tf.gradients derives (train.py:123-129) -- with the reduction done by the convolution's epilogue while the
+ * tile is still on chip (partial rows in bn_part, f32 [2][YOLO2_BN_PART_ROWS][Nf], zero on entry and on return), so dX and
+ * Yprev are not re-read by a separate pass.  Shapes the epilogue cannot take (Nf % (16/elem size) != 0, K-sliced grids) run
+ * the two-step form internally with red_ws (>= yolo2_bn_workspace_bytes(Nf)): the results are the same up to summation order.
+ * Yprev: [B*H*W][Nf] (pixel stride Nf).  pending: NULL -> dgamma/dbeta are final on return (stream order).  Non-NULL -> the
+ * caller finishes: *pending = 1 means the sums are still in bn_part and yolo2_bn_part_to_grads must follow (a caller timing
+ * the convolution launch alone brackets just this call); 0 means dgamma/dbeta were already written by the two-step form. */
+int yolo2_conv2d_dgrad_bn(const void *dY, const void *F, void *dX, float *ws, size_t ws_bytes, int B, int H, int W, int Cp, int ldp,
+                          int Nf, int ldo, int ksize, const void *Yprev, const float *mean, const float *var, const float *gamma,
+                          const float *beta, float *dgamma, float *dbeta, float *bn_part, double *red_ws, float eps, float alpha,
+                          int *pending, int dtype, void *stream);
+/* column sums of the partial rows left by yolo2_conv2d_dgrad_bn: plane 0 -> dgamma, plane 1 -> dbeta; rows zeroed again */
+int yolo2_bn_part_to_grads(float *bn_part, int C, float *dgamma, float *dbeta, void *stream);
+
 /* Forward convolution of a batch-normalised layer (no bias): as yolo2_conv2d_ws, and the per-channel shifted sums
  *   sum_m (y[m,n] - shift[n]),  sum_m (y[m,n] - shift[n])^2        (y = the stored, rounded output)
  * are accumulated into bn_part, f32 [2][YOLO2_BN_PART_ROWS][Nf], by the convolution's own epilogue (f32 atomics on

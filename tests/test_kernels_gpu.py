@@ -189,6 +189,58 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
     np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape,fused', [((2, 26, 26, 160, 64, 3), True),       # (B, H, W, filters of the consumer, channels = producer filters, k); M tail
+                                         ((16, 13, 13, 1024, 512, 3), True),   # stream-K (256 x 128 tiles): owners hold the finished tiles
+                                         ((8, 13, 13, 1024, 504, 3), True),    # stream-K, ragged filter tile
+                                         ((4, 52, 52, 256, 128, 3), True),     # full grid, wide rows
+                                         ((2, 26, 26, 512, 256, 1), True),
+                                         ((3, 20, 20, 64, 32, 3), True),       # 32-wide filter tile
+                                         ((2, 13, 13, 512, 256, 3), False)])   # K-sliced grid -> two-step form inside the call
+def test_conv_dgrad_bn_fused_sums(ops, shape, fused, mode):
+    """yolo2_conv2d_dgrad_bn == yolo2_conv2d_ws followed by yolo2_bn_leaky_bwd_reduce: the same dX bit for bit, dgamma / dbeta equal up
+    to the f32 summation order; the partial rows are zero again afterwards."""
+    B, H, W, Cout, Cin, k = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(sum(shape) + 11)
+    M = B * H * W
+    ldy, ldx = ops.pad8(Cout), ops.pad8(Cin)
+    dy = dev(pad_channels(rng.randn(B, H, W, Cout).astype(np.float32), ldy), tdtype)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cout)).astype(np.float32)
+    F = torch.zeros(Cin * k * k * ldy, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), None, F, k, Cin, ldx, Cout, ldy, tdtype)
+    yprev = dev(rng.randn(M, Cin).astype(np.float32) * 1.5 + 0.3, tdtype)
+    mean, var = dev(rng.randn(Cin).astype(np.float32) * 0.2 + 0.3), dev((rng.rand(Cin) + 0.5).astype(np.float32))
+    gamma, beta = dev((rng.rand(Cin) + 0.5).astype(np.float32)), dev(rng.randn(Cin).astype(np.float32) * 0.3)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    red = torch.zeros(ops.workspace_bytes('bn', Cin) // 8, dtype=torch.float64, device='cuda')
+    dx_ref = torch.zeros(M * ldx, dtype=tdtype, device='cuda')
+    ops.conv2d_ws(dy, F, None, dx_ref, ws, B, H, W, ldy, ldy, Cin, ldx, k)
+    dg_ref, db_ref = torch.zeros(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    ops.bn_leaky_bwd_reduce(dx_ref, ldx, yprev, mean, var, gamma, beta, dg_ref, db_ref, red, M, Cin, 1e-3, 0.1)
+    dx = torch.zeros(M * ldx, dtype=tdtype, device='cuda')
+    dg, db = torch.full((Cin,), 9.0, device='cuda'), torch.full((Cin,), 9.0, device='cuda')
+    part = torch.zeros(2 * 256 * Cin, dtype=torch.float32, device='cuda')
+    pending = ops.conv2d_dgrad_bn(dy, F, dx, ws, B, H, W, ldy, ldy, Cin, ldx, k, yprev, mean, var, gamma, beta, dg, db, part, red, 1e-3, 0.1)
+    plan = ops.last_conv_plan()
+    assert pending == bool(plan['split'] & 0x100), (pending, plan)
+    if mode == 'bf16':                     # (f32 tiles of some variants do not fit the LDS image: those run the two-step form)
+        assert pending == fused, (pending, plan)
+    if pending:
+        ops.bn_part_to_grads(part, Cin, dg, db)
+    torch.cuda.synchronize()
+    # (stream-K / K-sliced grids add partial tiles in a launch-dependent order: last-bit differences in dX between launches)
+    assert_close(host(dx), host(dx_ref), 1e-6 if mode == 'f32' else 8e-3, 'dgrad_bn dX %s %s' % (shape, mode))
+    assert float(part.abs().max()) == 0.0
+    if torch.equal(dx, dx_ref):
+        tol = 2e-5
+    else:                                  # a differently rounded dX element moves the sums by more than their summation-order noise
+        tol = 2e-4 if mode == 'f32' else 2e-2
+    for got, ref, name in ((dg, dg_ref, 'dgamma'), (db, db_ref, 'dbeta')):
+        g, r = host(got).astype(np.float64), host(ref).astype(np.float64)
+        assert np.abs(g - r).max() <= tol * np.abs(r).max(), (name, shape, mode, np.abs(g - r).max(), np.abs(r).max())
+
+
 WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]
 
 

@@ -78,13 +78,25 @@ template <> struct Mma<float> {
 #define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
+// Data-gradient launches whose output IS the gradient dA of a batch-normalised producer layer (a = leaky(bn(y))) can reduce that
+// layer's BN + leaky backward sums in their epilogue: Y non-NULL selects it.  Per output element dz = dA * leaky'(z),
+// xhat = (y - mean) * rstd; the tile adds its columns' sum(dz * xhat) [plane 0] and sum(dz) [plane 1] to the partial rows the
+// forward statistics use.  Replaces one full read of dA and y (bn_bwd_reduce_kernel) per layer with a read of y alone, issued while
+// the tile is still in LDS.
+struct Y2BnBwd {
+    const void *Y;      // pre-normalisation output of the producer layer, [M][Nf] (pixel stride = Nf)
+    const float *mean, *var, *gamma, *beta;
+    float eps, alpha;
+};
+
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
 // CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
-template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int CH = 4, int NW = 4, int BMv = 128>
+template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int CH = 4, int NW = 4, int BMv = 128, bool BNBWD = false>
 __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     const T *__restrict__ P, unsigned p_bytes, const T *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     T *__restrict__ O, float *__restrict__ Oacc, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT, int remap,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags, float act_alpha, int wide_store) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ sk_flags, float act_alpha, int wide_store,
+    const Y2BnBwd bz) {
     constexpr int BM = BMv;                // pixels per tile: 128, or 256 (8 waves of 64 x 64)
     constexpr int TAPS = KS * KS;
     constexpr int VEC = 16 / sizeof(T);
@@ -376,7 +388,8 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     // With bn_part != NULL (forward of a batch-normalised layer) the tile also contributes its columns' shifted sums
     // sum(y - shift), sum((y - shift)^2) of the STORED (rounded) outputs to one of Y2_BN_PART_ROWS partial rows: the
     // statistics pass over y (a full re-read of every activation, 21 launches per step) is gone.
-    const bool stats = SPLITK != 1 && bn_part != nullptr;
+    const bool stats = !BNBWD && SPLITK != 1 && bn_part != nullptr;
+    const bool bstats = BNBWD && SPLITK != 1 && bn_part != nullptr;      // (host: only with the wide-store epilogue below)
     // The partial rows are indexed by (pixel tile, wave row).  When those fit the 256 rows every (row, filter) has exactly one writer:
     // plain stores, bitwise-reproducible statistics -- and the f32 atomics of the 13x13 stages (each a fabric round trip) were 10 us of
     // a 77 us launch (profiles/r02_igemm_ablation.txt).  Larger layers wrap around the rows and keep the atomic adds.
@@ -434,6 +447,39 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     constexpr int WROWS = TM * 32, WROWB = TN * 32 * (int)sizeof(T), WSTRIDE = WROWB + 16, WCPR = WROWB / 16;
     constexpr bool WIDE_FITS = SPLITK != 1 && NW * WROWS * WSTRIDE <= NSTAGE * STAGE;
     if (WIDE_FITS && wide_store) {
+        // producer-layer operands of the fused BN-backward sums: this lane's VEC per-channel constants and the y vectors of the NIT
+        // (pixel, chunk) positions it stores below -- all issued back to back, consumed after the staging loop (one exposed latency per
+        // tile instead of one per store).  Stream-K workgroups (256 VGPRs per wave) issue them ahead of the staging loop.
+        constexpr int NIT = WROWS * WCPR / 64;
+        constexpr int YG = NIT < 4 ? NIT : 4;       // y vectors in flight per lane (the 256-pixel tile spills with all 8)
+        constexpr bool BZ_EARLY = SPLITK == 2 && BM == 128;
+        float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
+        Vec16<T> yv[YG];
+        const int bz_nb = min(n0 + wn * TN * 32 + (lane % WCPR) * VEC, Nf - VEC);      // (clamped: out-of-range chunks are never summed)
+        auto bz_load_y = [&](int it0) {
+#pragma unroll
+            for (int u = 0; u < YG; ++u) {
+                const int m = min(m0 + wm * WROWS + ((it0 + u) * 64 + lane) / WCPR, M - 1);
+                yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
+            }
+        };
+        auto bz_prefetch = [&]() {
+            bz_load_y(0);
+#pragma unroll
+            for (int k = 0; k < VEC; k += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + bz_nb + k), b = *reinterpret_cast<const f32x4 *>(bz.var + bz_nb + k);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + bz_nb + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + bz_nb + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cmu[k + q] = a[q];
+                    cinv[k + q] = 1.0f / sqrtf(b[q] + bz.eps);
+                    cga[k + q] = c[q];
+                    cbt[k + q] = d[q];
+                    ps[0][k + q] = ps[1][k + q] = 0.f;
+                }
+            }
+        };
+        if (bstats && BZ_EARLY) bz_prefetch();
         __syncthreads();                       // every wave has finished reading the last K step's stage
         unsigned char *wreg = smem + wave * (WROWS * WSTRIDE);
         const bool tail = m0 + BM > M;
@@ -472,6 +518,9 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
         }
         // (LDS operations of one wave execute in order: its own reads below see its own writes above)
+        // BN + leaky backward sums of the producer layer (bz): a lane keeps the same VEC filters in every iteration (64 % WCPR == 0)
+        static_assert(64 % WCPR == 0, "a lane stays on one column chunk");
+        if (bstats && !BZ_EARLY) bz_prefetch();
 #pragma unroll
         for (int it = 0; it < WROWS * WCPR / 64; ++it) {
             const int id = it * 64 + lane;
@@ -479,7 +528,42 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             const int m = m0 + wm * WROWS + row;
             const int n = n0 + wn * TN * 32 + ch * VEC;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
-            if (m < M && n < Nf) *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+            if (bstats && it && it % YG == 0) bz_load_y(it);
+            if (m < M && n < Nf) {
+                *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+                if (bstats) {      // same arithmetic as bn_bwd_reduce_kernel (elementwise.hip), on the rounded gradient just stored
+                    const Vec16<T> y = yv[it % YG];
+                    Vec16<T> d;
+                    d.v = __builtin_bit_cast(decltype(d.v), v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float xh = (y.get(k) - cmu[k]) * cinv[k];
+                        const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
+                        const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
+                        ps[0][k] += g * xh;
+                        ps[1][k] += g;
+                    }
+                }
+            }
+        }
+        if (bstats) {
+#pragma unroll
+            for (int off = WCPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    ps[0][k] += __shfl_xor(ps[0][k], off, 64);
+                    ps[1][k] += __shfl_xor(ps[1][k], off, 64);
+                }
+            const int nb = n0 + wn * TN * 32 + lane * VEC;
+            if (lane < WCPR && nb < Nf) {
+                const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (stats_unique) { p1[k] = ps[0][k]; p2[k] = ps[1][k]; }
+                    else { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
+                }
+            }
         }
     } else if (m0 + BM <= M) write_tile(std::false_type{});
     else write_tile(std::true_type{});
@@ -572,13 +656,23 @@ static int choose_ksplit(int tiles, int nk, int target) {
 // the plan of the calling thread's most recent launch (yolo2_debug_last_conv_plan): tests assert that the variant they
 // mean to check is the one that ran, since the choice is shape-driven
 static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define Y2_IGEMM_ARGS (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
     do {                                                                                                           \
         const dim3 g_ = (gridv);                                                                                   \
         const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
         for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
-        conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv><<<g_, NWv * 64, 0, st>>>(          \
-            (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift, bn_part, sk_flags, act_alpha, wide_store); \
+        if (!bz.Y)                                                                                                 \
+            conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
+                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz);                                      \
+        else if (SPLITv != 1 && !CTv && wide_store && igemm_wide_fits<T, BMv, BNv, WGNv, NSv, CHv, NWv>())         \
+            conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, (SPLITv == 1 ? 0 : SPLITv), false, CHv, NWv, BMv, true><<<g_, NWv * 64, 0, st>>>( \
+                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz);                                      \
+        else {      /* this variant has no on-chip tile image to reduce from: the caller runs the two-step form */ \
+            *stats_done = false;                                                                                   \
+            conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
+                Y2_IGEMM_ARGS, nullptr, sk_flags, act_alpha, wide_store, Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}); \
+        }                                                                                                          \
     } while (0)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
 // kernel size x channel tail (4-chunk rows only; 8-chunk rows require Cp % (8*VEC) == 0)
@@ -598,9 +692,18 @@ static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         else Y2_IGEMM(128, 2, 3, 1, SPLITv, false, 8, 8, gridv);                       \
     } while (0)
 
+// does this instantiation have the LDS-transposed (wide-store) epilogue?  (mirror of WIDE_FITS in the kernel)
+template <typename T, int BMv, int BN, int WGN, int NSTAGE, int CH, int NW>
+static constexpr bool igemm_wide_fits() {
+    constexpr int RPI = 64 / CH, ROWB = CH * 16, WGM = NW / WGN, TM = BMv / WGM / 32, TN = BN / WGN / 32;
+    constexpr int B_IT = (BN / RPI + NW - 1) / NW, STAGE = (BMv + B_IT * NW * RPI) * ROWB;
+    return NW * (TM * 32) * (TN * 32 * (int)sizeof(T) + 16) <= NSTAGE * STAGE;
+}
+
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
-                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done, float act_alpha) {
+                       int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done, float act_alpha,
+                       const Y2BnBwd bz = Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
@@ -690,7 +793,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
 
 static int conv2d_impl(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H,
                        int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn,
-                       const float *bn_shift = nullptr, float *bn_part = nullptr, float act_alpha = 1.0f) {
+                       const float *bn_shift = nullptr, float *bn_part = nullptr, float act_alpha = 1.0f, const Y2BnBwd *bwd = nullptr,
+                       float *dgamma = nullptr, float *dbeta = nullptr, double *red_ws = nullptr, int *pending = nullptr) {
     if (!(P && F && O) || !(B > 0 && H > 0 && W > 0 && Cp > 0 && Nf > 0) || !(ksize == 1 || ksize == 3) || !(ldp >= Cp && ldo >= Nf)) {
         yolo2_set_error("%s: argument check failed: pointers / extents / ksize / strides", fn);
         return YOLO2_E_ARG;
@@ -706,7 +810,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     }
     int rc = 0;
     static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
-    if (first_direct && !bias && act_alpha == 1.0f && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
+    if (first_direct && !bias && !bwd && act_alpha == 1.0f && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
         for (int i = 0; i < 8; ++i) g_last_plan[i] = -1;      // direct first-layer kernel (conv_first.hip)
@@ -714,6 +818,26 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         return YOLO2_OK;
     }
     bool stats_done = true;
+    if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
+        static const bool fuse = !(getenv("YOLO2_FUSE_BN_BWD") && atoi(getenv("YOLO2_FUSE_BN_BWD")) == 0);
+        const bool can = fuse && Nf % vec == 0;
+        if (can) {
+            Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
+                                                         nullptr, bn_part, &stats_done, act_alpha, *bwd));
+        } else {
+            stats_done = false;
+            Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
+                                                         nullptr, nullptr, &stats_done, act_alpha));
+            stats_done = false;
+        }
+        if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
+        Y2_CHECK_LAUNCH();
+        g_last_plan[5] |= stats_done ? 0x100 : 0;      // plan word 5 (split mode): bit 8 = the sums came from the epilogue
+        if (pending) *pending = stats_done ? 1 : 0;
+        if (stats_done) return pending ? YOLO2_OK : y2_bn_part_to_grads(bn_part, Nf, dgamma, dbeta, (hipStream_t)stream);
+        return yolo2_bn_leaky_bwd_reduce(O, ldo, bwd->Y, bwd->mean, bwd->var, bwd->gamma, bwd->beta, dgamma, dbeta, red_ws, (long)B * H * W, Nf,
+                                         bwd->eps, bwd->alpha, dtype, stream);
+    }
     Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
                                                  bn_shift, bn_part, &stats_done, act_alpha));
     if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
@@ -755,6 +879,23 @@ extern "C" int yolo2_conv2d_bn(const void *P, const void *F, void *O, float *ws,
         return YOLO2_E_ARG;
     }
     return conv2d_impl(P, F, nullptr, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_bn", shift, bn_part);
+}
+
+extern "C" int yolo2_conv2d_dgrad_bn(const void *dY, const void *F, void *dX, float *ws, size_t ws_bytes, int B, int H, int W, int Cp, int ldp,
+                                     int Nf, int ldo, int ksize, const void *Yprev, const float *mean, const float *var, const float *gamma,
+                                     const float *beta, float *dgamma, float *dbeta, float *bn_part, double *red_ws, float eps, float alpha,
+                                     int *pending, int dtype, void *stream) {
+    if (!Yprev || !mean || !var || !gamma || !beta || !dgamma || !dbeta || !bn_part || !red_ws) {
+        yolo2_set_error("yolo2_conv2d_dgrad_bn: argument check failed: a producer-layer pointer is NULL");
+        return YOLO2_E_ARG;
+    }
+    const Y2BnBwd bz{Yprev, mean, var, gamma, beta, eps, alpha};
+    return conv2d_impl(dY, F, nullptr, dX, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_dgrad_bn", nullptr, bn_part, 1.0f,
+                       &bz, dgamma, dbeta, red_ws, pending);
+}
+extern "C" int yolo2_bn_part_to_grads(float *bn_part, int C, float *dgamma, float *dbeta, void *stream) {
+    if (!bn_part || !dgamma || !dbeta || C <= 0) { yolo2_set_error("yolo2_bn_part_to_grads: argument check failed"); return YOLO2_E_ARG; }
+    return y2_bn_part_to_grads(bn_part, C, dgamma, dbeta, (hipStream_t)stream);
 }
 
 extern "C" int yolo2_conv2d_bias_leaky(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,

@@ -377,6 +377,7 @@ int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, flo
 }
 
 // partial rows -> batch mean / biased variance (+ moving-average update), and the rows are zeroed again for the next step
+template <int FIN>      // 0: batch moments (+ moving averages); 1: plain column sums (plane 0 -> mean_out, plane 1 -> var_out)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(float *__restrict__ part, const float *__restrict__ shift, int C, long M,
                                                           float *__restrict__ mean_out, float *__restrict__ var_out,
                                                           float *__restrict__ mm, float *__restrict__ mv, float omd) {
@@ -414,6 +415,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float *__restrict__ pa
             for (int r = 0; r < 16; ++r) a += red[k][r][col];
             t[k] = a;
         }
+        if (FIN == 1) {
+            mean_out[c] = (float)t[0];
+            var_out[c] = (float)t[1];
+            return;
+        }
         const double dm = t[0] / (double)M;
         const double var = t[1] / (double)M - dm * dm;
         const double mean = (double)shift[c] + dm;
@@ -430,7 +436,13 @@ extern "C" int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int
                                  float *moving_var, double decay, void *stream) {
     Y2_CHECK_ARG(bn_part && shift && mean && var && M > 0 && C > 0);
     Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr));
-    bn_finalize_kernel<<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(bn_part, shift, C, M, mean, var, moving_mean, moving_var, (float)(1.0 - decay));
+    bn_finalize_kernel<0><<<cdiv(C, 16), 256, 0, (hipStream_t)stream>>>(bn_part, shift, C, M, mean, var, moving_mean, moving_var, (float)(1.0 - decay));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+int y2_bn_part_to_grads(float *part, int C, float *dgamma, float *dbeta, hipStream_t st) {
+    bn_finalize_kernel<1><<<cdiv(C, 16), 256, 0, st>>>(part, nullptr, C, 1, dgamma, dbeta, nullptr, nullptr, 0.f);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

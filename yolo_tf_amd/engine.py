@@ -176,6 +176,7 @@ class Engine(object):
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
             self.side_stream = torch.cuda.Stream(device=dev)
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
+            self.overlap_max_m = int(os.environ.get('YOLO2_OVERLAP_MAX_M', str(1 << 40)))   # A/B: overlap only layers with at most this many output pixels
         self.img = None
 
     def _bind(self, graph):
@@ -208,8 +209,23 @@ class Engine(object):
                     need = B * (x.h // 2) * (x.w // 2) * x.c
                     if self.training and ('pool_idx' not in st or st['pool_idx'].numel() < need):
                         st['pool_idx'] = torch.zeros(need, dtype=torch.uint8, device=dev)
+        # BN-backward sums in the consumer's data-gradient epilogue: a batch-normalised conv whose full-resolution activation has
+        # exactly one reader, a convolution writing that activation's gradient directly (no concat slice, no fan-out)
+        bn_bwd_fused = {}
+        if self.training and os.environ.get('YOLO2_FUSE_BN_BWD', '1') != '0':
+            uses = {}
+            for op in graph.ops:
+                for t in (op.get('inputs') or [op['x']]):
+                    uses[t] = uses.get(t, 0) + 1
+            producers = {op['out']: op for op in graph.ops if op['kind'] == 'conv'}
+            for op in graph.ops:
+                x = op.get('x')
+                if (op['kind'] == 'conv' and x in producers and producers[x]['bn'] and 'fold_bias' not in self.conv[producers[x]['name']]
+                        and uses.get(x, 0) == 1 and x not in fused_pool and x in gact and gact[x][1] == x.c and act[producers[x]['y']][1] == x.c):
+                    bn_bwd_fused[op['name']] = producers[x]
         inp = next(iter(graph.inputs.values()))
-        self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {}}
+        self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {},
+                                          'bn_bwd_fused': bn_bwd_fused}
         self._use(inp.h, inp.w)
 
     def _use(self, h, w):
@@ -217,6 +233,7 @@ class Engine(object):
         self._cur = bnd
         self.graph, self.act, self.gact, self.fused_pool = bnd['graph'], bnd['act'], bnd['gact'], bnd['fused_pool']
         self._zero_ranges, self.tmp_grad = bnd['zero_ranges'], bnd['tmp_grad']
+        self.bn_bwd_fused = bnd['bn_bwd_fused']
 
     def add_size(self, graph):
         """Multi-scale training (BASELINE configs[3]): binds another traced input size of the SAME network (same variables, any
@@ -235,7 +252,7 @@ class Engine(object):
         self._use(height, width)
 
     # ---------------------------------------------------------------- helpers
-    def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k, bn_shift=None):
+    def _conv(self, P, F, bias, O, H, W, Cp, ldp, Nf, ldo, k, real_k, bn_shift=None, bn_bwd=None):
         """yolo2_conv2d launch; when a timer is attached, the 3x3 launches that take the 128-wide filter tile (Nf > 64:
         conv_igemm_kernel<.., KS = 3, ..>, the kernel that carries 64 % of the training FLOPs; the filter gradient carries
         most of the rest) are bracketed by HIP events; the 1x1 launches are tagged separately.
@@ -243,12 +260,19 @@ class Engine(object):
         t = self.kernel_timer if Nf > 64 else None
         if t is not None:
             t.start(2.0 * self.B * H * W * Nf * real_k, self._phase if k == 3 else '1x1')
+        pending = False
         if bn_shift is not None:     # training forward of a batch-normalised layer: statistics from the conv epilogue
             ops.conv2d_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, bn_shift, self.bn_part)
+        elif bn_bwd is not None:     # data gradient + the producer layer's dgamma / dbeta sums from the same epilogue
+            y, mean, var, gamma, beta, dgam, dbet = bn_bwd
+            pending = ops.conv2d_dgrad_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, y, mean, var, gamma, beta, dgam, dbet,
+                                          self.bn_part, self.ws, BN_EPS, LEAKY_ALPHA)
         else:
             ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
         if t is not None:
             t.stop()
+        if pending:
+            ops.bn_part_to_grads(self.bn_part, Nf, bn_bwd[5], bn_bwd[6])
 
     def _prepare_filters(self):
         """HWIO f32 masters -> both MFMA operand layouts of every layer, one launch (descriptor table built once)."""
@@ -429,6 +453,7 @@ class Engine(object):
         gradients are enqueued; ``event`` (or None) completes when they are final."""
         B = self.B
         written = set()
+        reduced = set()
         inputs = set(self.graph.inputs.values())
         self._phase = 'dgrad'
         self.reg_loss.zero_()
@@ -454,6 +479,8 @@ class Engine(object):
                         dpb, lddp = self.gact[pool['out']]
                         ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,
                                                      B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
+                    elif op['name'] in reduced:
+                        pass                  # dgamma / dbeta came out of the consumer's data-gradient epilogue
                     else:
                         ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
                     slot = (slot + 1) % 3
@@ -482,7 +509,7 @@ class Engine(object):
                     ops.bias_grad(dy, ldy, self.gvar[op['biases'].name], self.ws, M, cout)
                     ring = False
                 done = None
-                if side is not None:
+                if side is not None and M <= self.overlap_max_m:
                     ready = torch.cuda.Event()
                     ready.record(main)
                     side.wait_event(ready)
@@ -497,8 +524,16 @@ class Engine(object):
                     ops.conv2d_wgrad(xb, dy, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], ldx, cout, ldy, k)
                     self._l2(op)
                 if x not in inputs:
+                    prod = self.bn_bwd_fused.get(op['name'])
                     dst, ldd, fin = self._grad_sink(x, written)
-                    self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
+                    if prod is not None and fin is None:
+                        pst = self.conv[prod['name']]
+                        self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout,
+                                   bn_bwd=(self.act[prod['y']][0], pst['mean'], pst['var'], self.var[prod['gamma'].name], self.var[prod['beta'].name],
+                                           self.gvar[prod['gamma'].name], self.gvar[prod['beta'].name]))
+                        reduced.add(prod['name'])
+                    else:
+                        self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
                     if fin:
                         fin()
                 if on_layer_done is not None:

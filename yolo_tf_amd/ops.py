@@ -35,6 +35,19 @@ def conv2d_bn(P, F, O, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, shift, bn_part):
          ptr(shift), ptr(bn_part), dtype_code(P.dtype), _stream())
 
 
+def conv2d_dgrad_bn(dY, F, dX, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, Yprev, mean, var, gamma, beta, dgamma, dbeta, bn_part, red_ws, eps, alpha):
+    """-> True when the sums are still in ``bn_part`` (finish with ``bn_part_to_grads``)."""
+    pending = ctypes.c_int(0)
+    call('yolo2_conv2d_dgrad_bn', ptr(dY), ptr(F), ptr(dX), ptr(ws), ws.numel() * ws.element_size(), B, H, W, Cp, ldp, Nf, ldo, ksize,
+         ptr(Yprev), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta), ptr(bn_part), ptr(red_ws), eps, alpha,
+         ctypes.byref(pending), dtype_code(dY.dtype), _stream())
+    return bool(pending.value)
+
+
+def bn_part_to_grads(bn_part, C, dgamma, dbeta):
+    call('yolo2_bn_part_to_grads', ptr(bn_part), C, ptr(dgamma), ptr(dbeta), _stream())
+
+
 def bn_finalize(bn_part, shift, M, C, mean, var, mm, mv, decay):
     call('yolo2_bn_finalize', ptr(bn_part), ptr(shift), M, C, ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, _stream())
 
