@@ -114,8 +114,8 @@ def test_forward_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
         assert np.abs(host(var) - v_ref).max() <= 1e-4 * v_ref.max()
         assert float(part.abs().max()) == 0.0
     if name in ('conv18_19', 'conv20') and B == 16:
-        # the launches that carry the benchmark: 256x128 stream-K, one workgroup per CU
-        assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8, plan
+        # the launches that carry the benchmark: tap-fused 256x128 stream-K, one workgroup per CU ('stages' 9 = nine taps per halo image)
+        assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8 and plan['stages'] == 9, plan
     if name == 'conv13_15_17' and B == 16:
         assert plan['split'] == 2 and plan['BM'] == 128, plan      # 176 tiles for 256 CUs: stream-K on the 128x128 tile
 
@@ -137,7 +137,7 @@ def test_dgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     assert np.all(got[..., cin:] == 0)
     check_act(got[..., :cin], R.conv2d_dgrad(dy, w), 'dgrad %s %s' % (cname, name))
     if name in ('conv18_19', 'conv20') and B == 16:
-        assert plan['BM'] == 256 and plan['split'] == 2, plan
+        assert plan['BM'] == 256 and plan['split'] == 2 and plan['stages'] == 9, plan
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', list(_cases()))

@@ -189,6 +189,92 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
     np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
 
 
+TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 256), (8, 13, 13, 1024, 504), (16, 26, 26, 256, 136),
+              (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256)]
+
+
+@pytest.mark.parametrize('epilogue', ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn'])
+@pytest.mark.parametrize('shape', TAP_SHAPES)
+def test_conv_tap_fused_3x3(ops, shape, epilogue):
+    """conv3x3_tap_kernel (one halo image per 64-channel chunk, nine taps read from it) against the per-tap kernel on the same
+    operands -- same products, a different f32 summation order across stream-K segments only -- and against the oracle."""
+    B, H, W, Cin, Cout = shape
+    k, M = 3, B * H * W
+    rng = np.random.RandomState(sum(shape) + 3)
+    x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
+    w = bf16_round((rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32))
+    T = torch.bfloat16
+    ldo = ops.pad8(Cout)
+    F = torch.zeros(Cout * k * k * Cin, dtype=T, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, ldo, T)
+    xd = dev(x, T)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    bias = dev(rng.randn(Cout).astype(np.float32))
+    out = {}
+    for tap in (0, 1):
+        ops.set_igemm_tap(tap)     # (run with YOLO2_IGEMM_TAP_MIN_STEPS=0 YOLO2_IGEMM_TAP_MIN_SHARE=12 to force the short reductions through it too)
+        try:
+            O = torch.zeros(M * ldo, dtype=T, device='cuda')
+            extra = None
+            if epilogue == 'plain':
+                ops.conv2d_ws(xd, F, None, O, ws, B, H, W, Cin, Cin, Cout, ldo, k)
+            elif epilogue == 'bias_leaky':
+                ops.conv2d_bias_leaky(xd, F, bias, O, ws, B, H, W, Cin, Cin, Cout, ldo, k, 0.1)
+            elif epilogue == 'bn_stats':
+                if ldo != Cout:
+                    pytest.skip('batch-normalised outputs are stored unpadded')
+                part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
+                shift = dev(rng.randn(Cout).astype(np.float32) * 0.05) if tap == 0 else out[0][2][3]
+                mean, var = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+                ops.conv2d_bn(xd, F, O, ws, B, H, W, Cin, Cin, Cout, Cout, k, shift, part)
+                ops.bn_finalize(part, shift, M, Cout, mean, var, None, None, 0.999)
+                extra = (mean, var, part, shift)
+            else:
+                if ldo != Cout:
+                    pytest.skip('producer activations are stored unpadded')
+                if tap == 0:
+                    yprev = dev(rng.randn(M, Cout).astype(np.float32) * 1.5 + 0.3, T)
+                    pm, pv = dev(rng.randn(Cout).astype(np.float32) * 0.2 + 0.3), dev((rng.rand(Cout) + 0.5).astype(np.float32))
+                    pg, pb = dev((rng.rand(Cout) + 0.5).astype(np.float32)), dev(rng.randn(Cout).astype(np.float32) * 0.3)
+                else:
+                    yprev, pm, pv, pg, pb = out[0][2][4:]
+                part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
+                red = torch.zeros(ops.workspace_bytes('bn', Cout) // 8, dtype=torch.float64, device='cuda')
+                dg, db = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+                if ops.conv2d_dgrad_bn(xd, F, O, ws, B, H, W, Cin, Cin, Cout, ldo, k, yprev, pm, pv, pg, pb, dg, db, part, red, 1e-3, 0.1):
+                    ops.bn_part_to_grads(part, Cout, dg, db)
+                extra = (dg, db, part, None, yprev, pm, pv, pg, pb)
+            plan = ops.last_conv_plan()
+            torch.cuda.synchronize()
+            takes_tap = tap and (9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_STEPS', 144))
+                                 and -(-M // 256) * -(-Cout // 128) * 9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_SHARE', 40)) * 256)
+            assert (plan['stages'] == 9) == bool(takes_tap), plan
+            out[tap] = (host(O).reshape(M, ldo), plan, extra)
+        finally:
+            ops.set_igemm_tap(1)
+    y0, y1 = out[0][0], out[1][0]
+    assert np.all(y1[:, Cout:] == 0)
+    assert_close(y1, y0, 8e-3, 'tap-fused vs per-tap %s %s' % (shape, epilogue))     # one bf16 ulp where the f32 sums round differently
+    assert np.mean(y1 != y0) < 0.02
+    if epilogue in ('plain', 'bias_leaky') and M * Cin * Cout <= 16 * 169 * 512 * 1024:
+        ref = R.conv2d(x, w).reshape(M, Cout)
+        if epilogue == 'bias_leaky':
+            ref = ref + host(bias)
+            ref = np.maximum(ref, 0.1 * ref)
+        assert_close(y1[:, :Cout], ref, BF16_RTOL, 'tap-fused vs oracle %s %s' % (shape, epilogue))
+    if epilogue == 'bn_stats':
+        for a, b, name in ((out[1][2][0], out[0][2][0], 'mean'), (out[1][2][1], out[0][2][1], 'var')):
+            assert np.abs(host(a) - host(b)).max() <= 2e-3 * np.abs(host(b)).max() + 1e-5, name
+        assert float(out[1][2][2].abs().max()) == 0.0
+        yh = y1.astype(np.float64)
+        assert np.abs(host(out[1][2][0]) - yh.mean(0)).max() <= 2e-5 * np.sqrt(yh.var(0)).max() + 1e-6
+        assert np.abs(host(out[1][2][1]) - yh.var(0)).max() <= 1e-4 * yh.var(0).max()
+    if epilogue == 'dgrad_bn':
+        for a, b, name in ((out[1][2][0], out[0][2][0], 'dgamma'), (out[1][2][1], out[0][2][1], 'dbeta')):
+            assert np.abs(host(a) - host(b)).max() <= 2e-2 * np.abs(host(b)).max(), name
+        assert float(out[1][2][2].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape,fused', [((2, 26, 26, 160, 64, 3), True),       # (B, H, W, filters of the consumer, channels = producer filters, k); M tail
                                          ((16, 13, 13, 1024, 512, 3), True),   # stream-K (256 x 128 tiles): owners hold the finished tiles

@@ -87,6 +87,7 @@ QUERIES = {
     'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
     'yolo2_debug_set_wgrad_variant': (None, [_i]),
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
+    'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_conv2d_workspace_bytes': (ctypes.c_size_t, [_i] * 7),
     'yolo2_bn_workspace_bytes': (ctypes.c_size_t, [_i]),

@@ -48,6 +48,8 @@ __device__ __forceinline__ bf16x8 y2_frag16(u32x2 lo, u32x2 hi) {
 __device__ __forceinline__ unsigned y2_lds_addr(const void *p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
+#else
+__device__ inline unsigned y2_lds_addr(const void *) { return 0u; }      // (host pass of a __global__ body)
 #endif
 
 // first-layer direct convolution (conv_first.hip), used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches

@@ -239,6 +239,11 @@ def last_conv_plan():
     return dict(zip(CONV_PLAN_KEYS, list(out)))
 
 
+def set_igemm_tap(on):
+    """Test hook: tap-fused 3x3 implicit-GEMM variant on / off (process-wide)."""
+    _lib.load().yolo2_debug_set_igemm_tap(int(bool(on)))
+
+
 def last_wgrad_plan():
     out = (ctypes.c_int * 8)()
     _lib.load().yolo2_debug_last_wgrad_plan(out)
