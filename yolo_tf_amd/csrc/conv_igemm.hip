@@ -597,6 +597,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
 #define Y2T_BM 256
 #define Y2T_BN 128
 #define Y2T_BBYTES (Y2T_BN * 128)
+#define Y2T_DMA_EARLY 0
 #define Y2T_LOADS 3                        // per wave per K step: 1 halo slot + 2 filter pieces
 // HROWS = halo rows held (>= 256 + 2 W + 2), NSB = filter ring depth: (368, 4) for images up to 55 wide; (312, 5) up to 27 wide,
 // whose smaller halo buys a fifth ring stage = DMA four steps ahead of the MFMAs instead of three (160 KiB of LDS either way)
@@ -803,21 +804,21 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
         __builtin_amdgcn_s_barrier();                    // ... for every wave; nobody reads step kt-1's operands any more
 #endif
         __builtin_amdgcn_sched_barrier(0);
-#if !(Y2_TABL & 4)
-        issue_slot(c_tap, c_chunk + 1, kt + NSB - 1, bstage_i);
-#endif
-        bstage_i = bstage_i == NSB - 1 ? 0 : bstage_i + 1;
-        __builtin_amdgcn_sched_barrier(0);
         FragAddr ad_new;
         next_step(n_chunk, n_tap);
+        // fragment reads first (two behind each of eight MFMAs), the DMA slot after the last of them: a DMA piece issued while
+        // ds_reads are queued costs the wave 100-185 cycles of issue, 25-60 in a read-free gap (MI355X_MICROARCH.md)
 #pragma unroll
         for (int g = 0; g < 12; ++g) {
             mfma_one(1 + g / 4, g & 3);
-            if (g < 4) { read_one(2 * g); read_one(2 * g + 1); }
-            else read_one(g + 4);
-            if (g == 5) calc_addr(ad_new, n_chunk, n_tap, bstage_n);          // step kt+2
+            if (g < 8) { read_one(2 * g); read_one(2 * g + 1); }
+            if (g == 8) calc_addr(ad_new, n_chunk, n_tap, bstage_n);          // step kt+2
+#if !(Y2_TABL & 4)
+            if (g == 9 + (Y2T_DMA_EARLY ? -100 : 0)) issue_slot(c_tap, c_chunk + 1, kt + NSB - 1, bstage_i);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+        bstage_i = bstage_i == NSB - 1 ? 0 : bstage_i + 1;
         ad_next = ad_new;
         bstage_n = bstage_n == NSB - 1 ? 0 : bstage_n + 1;
         next_step(c_chunk, c_tap);
