@@ -731,8 +731,10 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
         for (int i = 0; i < TM; ++i) {
             const unsigned hb = rowb[i] + toffb;                      // halo row * 128
             const bool ok = (amask & (tbit << (16 * i))) != 0u;
-            fa_.abase[i] = ok ? hb + hbase : lds0 + (unsigned)ZERO;   // masked (pixel, tap): the zero chunk
-            fa_.ax[i] = (ok ? ((hb >> 4) & 0x70u) : 0u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane's half of the k group
+            // masked (pixel, tap): the zero KiB, at the SAME offset inside a 256-byte bank line as the real row (one fixed zero chunk
+            // for every masked lane collided with the other lanes' banks: SQ_LDS_BANK_CONFLICT 19 % of the LDS cycles on 13x13 images)
+            fa_.abase[i] = ok ? hb + hbase : lds0 + (unsigned)ZERO + (hb & 0x80u);
+            fa_.ax[i] = ((hb >> 4) & 0x70u) ^ hi16;                   // ((row >> 1) & 7) << 4, folded with this lane's half of the k group
         }
         fa_.bbase = brow + (unsigned)(bs * Y2T_BBYTES);
     };
