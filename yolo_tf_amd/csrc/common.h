@@ -31,7 +31,7 @@ __device__ __forceinline__ u32x2 y2_tr16_read(unsigned lds_addr) {
 }
 template <int OFF> __device__ __forceinline__ u32x2 y2_tr16_read_off(unsigned lds_addr) {
     u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(lds_addr), "n"(OFF) : "memory");     // (&: the address register is re-used by the next read)
     return v;
 }
 // wait until at most N LDS operations of this wave are outstanding; a, b (and c, d): the registers whose data this wait covers

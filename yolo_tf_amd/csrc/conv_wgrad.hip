@@ -195,24 +195,54 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
             // made hipcc put `s_waitcnt vmcnt(0)` in front of the first read of every tile -- the DMA ring was drained each
             // iteration and the counted vmcnt above never had anything to count.  All reads of the tile are issued first, each K
             // step's MFMAs wait only for their own fragments.
+            // Address of read (ks, r) = the lane's address of read (0, 0) + (16 ks + 4 r) pixel rows: the swizzle term depends on the
+            // pixel row modulo RPL * SWM = 4 only, so it is the same for every (ks, r) and the row step goes into the instruction's
+            // offset field -- one address add per fragment row and K step instead of one per read (12 of the ~85 instructions a
+            // wave spends per four MFMAs; the kernels are instruction-issue bound, profiles/r02_igemm_tap.md section 3).
             constexpr int KSN = BKP / 16;
+            static_assert(4 % (XRPL * XSWM) == 0 && 4 % (YRPL * YSWM) == 0, "the swizzle period (in pixel rows) divides the 4-row read step");
             u32x2 ra[KSN][TM][2], rb[KSN][TN][2];
+            unsigned xa[TM], ya[TN];
+            {
+                const int px = 8 * (g >> 1) + (t >> 2);
+                const int co = 16 * (g & 1) + 4 * (t & 3);                   // channel offset inside a 32-wide MFMA tile
+                const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int ch = (wm * TM + i) * 32 + co;
+                    xa[i] = y2_lds_addr(Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int ch = (wn * TN + j) * 32 + co;
+                    ya[j] = y2_lds_addr(Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1));
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
-                    const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t >> 2);
-                    const int co = 16 * (g & 1) + 4 * (t & 3);               // channel offset inside a 32-wide MFMA tile
-                    const int xsw = ((px / XRPL) % XSWM) * 4, ysw = ((px / YRPL) % YSWM) * 4;
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
-                        const int ch = (wm * TM + i) * 32 + co;
-                        ra[ks][i][r] = y2_tr16_read(y2_lds_addr(Xs + px * XROWB + (((ch >> 3) ^ xsw) << 4) + ((ch & 7) << 1)));
+                        if (ks == 0 && r == 0) ra[ks][i][r] = y2_tr16_read_off<0>(xa[i]);
+                        else if (ks == 0) ra[ks][i][r] = y2_tr16_read_off<4 * XROWB>(xa[i]);
+                        else if (ks == 1 && r == 0) ra[ks][i][r] = y2_tr16_read_off<16 * XROWB>(xa[i]);
+                        else if (ks == 1) ra[ks][i][r] = y2_tr16_read_off<20 * XROWB>(xa[i]);
+                        else if (ks == 2 && r == 0) ra[ks][i][r] = y2_tr16_read_off<32 * XROWB>(xa[i]);
+                        else if (ks == 2) ra[ks][i][r] = y2_tr16_read_off<36 * XROWB>(xa[i]);
+                        else if (r == 0) ra[ks][i][r] = y2_tr16_read_off<48 * XROWB>(xa[i]);
+                        else ra[ks][i][r] = y2_tr16_read_off<52 * XROWB>(xa[i]);
                     }
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const int ch = (wn * TN + j) * 32 + co;
-                        rb[ks][j][r] = y2_tr16_read(y2_lds_addr(Ys + px * YROWB + (((ch >> 3) ^ ysw) << 4) + ((ch & 7) << 1)));
+                        if (ks == 0 && r == 0) rb[ks][j][r] = y2_tr16_read_off<0>(ya[j]);
+                        else if (ks == 0) rb[ks][j][r] = y2_tr16_read_off<4 * YROWB>(ya[j]);
+                        else if (ks == 1 && r == 0) rb[ks][j][r] = y2_tr16_read_off<16 * YROWB>(ya[j]);
+                        else if (ks == 1) rb[ks][j][r] = y2_tr16_read_off<20 * YROWB>(ya[j]);
+                        else if (ks == 2 && r == 0) rb[ks][j][r] = y2_tr16_read_off<32 * YROWB>(ya[j]);
+                        else if (ks == 2) rb[ks][j][r] = y2_tr16_read_off<36 * YROWB>(ya[j]);
+                        else if (r == 0) rb[ks][j][r] = y2_tr16_read_off<48 * YROWB>(ya[j]);
+                        else rb[ks][j][r] = y2_tr16_read_off<52 * YROWB>(ya[j]);
                     }
                 }
 #pragma unroll
