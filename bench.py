@@ -42,7 +42,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3
 # 1.00 on bn_leaky_kernel (profiles/r01_hbm_traffic_pmc_final.md: 99.1 MB fetched + 27.2 MB written per launch).  The counters
 # sit between L2 and the fabric: Infinity-Cache hits are included (the 3072-channel layer alone re-reads its filter slab from
 # the MALL 11 times: 0.8 GB).  Algorithmic bytes (every operand once): 31.9 MB, 40.4 GFLOP per launch.
-IGEMM_HBM_BYTES_PER_LAUNCH = 126.3e6
+IGEMM_HBM_BYTES_PER_LAUNCH = 123.4e6      # profiles/r02_hbm_traffic_pmc.md: FETCH_SIZE x 1024 x 2 (94.4 MB) + WRITE_SIZE x 1024 (29.0 MB), 24 launches
 IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 31.9e6
 TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
 
@@ -74,15 +74,40 @@ class KernelTimer(object):
         self.tags.append(self._cur[2])
         self._cur = None
 
+    NOOP_KERNEL_MS = 0.0034      # median duration rocprofv3 reports for the empty kernel itself (64 launches: 0.6 .. 6.9 us; profiles/r02_bench_roofline_check.txt)
+
+    def calibrate(self, n=64):
+        """What a bracket adds to the kernel inside it.  A HIP-event pair measures from the completion of the start event to the
+        completion of the stop event: the bracketed kernel's own duration (what rocprofv3's kernel trace reports) PLUS the dispatch
+        latency between the two (~3 us; more under a profiler's dispatch interception).  Measured on brackets around an empty kernel,
+        each issued behind a running kernel like the real ones: overhead = median bracket - the empty kernel's own 3.4 us."""
+        from yolo_tf_amd import ops
+        st = torch.cuda.current_stream()
+        filler = torch.zeros(1 << 22, device='cuda')
+        pairs = []
+        for _ in range(n):
+            filler.add_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            ops.noop()
+            b.record(st)
+            pairs.append((a, b))
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in pairs)
+        self.bracket_noop_ms = ms[len(ms) // 2]
+        self.bracket_overhead_ms = max(0.0, self.bracket_noop_ms - self.NOOP_KERNEL_MS)
+
     def summary(self, tag=None):
         tags = None if tag is None else (tag if isinstance(tag, tuple) else (tag,))
         sel = [i for i in range(len(self.pairs)) if tags is None or self.tags[i] in tags]
         if not sel:
             return None
-        ms = [self.pairs[i][0].elapsed_time(self.pairs[i][1]) for i in sel]
+        raw = [self.pairs[i][0].elapsed_time(self.pairs[i][1]) for i in sel]
+        ovh = getattr(self, 'bracket_overhead_ms', 0.0)
+        ms = [max(m - ovh, 0.0) for m in raw]
         fl = [self.flops[i] for i in sel]
         total_ms = float(sum(ms))
-        return {'launches': len(ms), 'avg_ms': total_ms / len(ms), 'total_ms': total_ms,
+        return {'launches': len(ms), 'avg_ms': total_ms / len(ms), 'total_ms': total_ms, 'raw_bracket_avg_ms': float(sum(raw)) / len(raw),
                 'tflops': float(sum(fl)) / (total_ms * 1e-3) / 1e12, 'flop_per_launch': float(sum(fl)) / len(ms)}
 
 
@@ -271,6 +296,7 @@ def main():
             sess.step(images)
         torch.cuda.synchronize()
         timer.enabled = False
+        timer.calibrate()
         sess.engine.overlap_wgrad = overlap
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
@@ -302,9 +328,17 @@ def main():
             kf, kd, k1 = timer.summary('fwd'), timer.summary('dgrad'), timer.summary('1x1')
             out['roofline'] = {'bound': 'mfma', 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak,
                                'traffic': IGEMM_HBM_BYTES_PER_LAUNCH if (args.dtype == 'bf16' and args.batch == 16 and args.size == 416) else None,
-                               'kernel': 'conv_igemm_kernel<%s, KS=3, ...> (3x3 implicit-GEMM forward + data-gradient convolutions with > 64 filters: '
-                                         'the "3x3 convs" of the north-star target)' % args.dtype,
+                               'kernel': 'conv_igemm_kernel<%s, BN=128, KS=3, ...> + conv3x3_tap_kernel<...> (the 3x3 implicit-GEMM forward + data-gradient '
+                                         'convolutions with > 64 filters: the "3x3 convs" of the north-star target; the tap-fused kernel takes the '
+                                         '>= 1024-channel 13x13 layers)' % args.dtype,
+                               'sustained_mfma_peak_note': 'a pure v_mfma_f32_32x32x16_bf16 loop sustains 1.9-2.1 PFLOP/s on these boxes (power-limited clock, '
+                                                           'profiles/r02_igemm_tap.md); peak above is the 2.4 GHz datasheet figure',
                                'launches': ks['launches'], 'avg_launch_ms': ks['avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
+                               'event_bracket': {'raw_avg_ms': ks['raw_bracket_avg_ms'], 'overhead_ms': timer.bracket_overhead_ms,
+                                                 'around_empty_kernel_ms': timer.bracket_noop_ms,
+                                                 'note': 'avg_launch_ms = HIP-event bracket minus the dispatch latency a bracket adds, calibrated on '
+                                                         'brackets around an empty kernel (its own 3.4 us excluded); frac from the raw brackets: %.4f'
+                                                         % (ks['tflops'] * ks['total_ms'] / (ks['raw_bracket_avg_ms'] * ks['launches']) / peak)},
                                'algorithmic_bytes_per_launch': IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH, 'traffic_unit': 'bytes per launch (PMC, separate passes)',
                                'measured_over': '%d instrumented single-stream training steps run right after the timed region '
                                                 '(events inside it cost 11 %% of the step)' % min(args.steps, 10),

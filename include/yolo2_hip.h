@@ -330,6 +330,8 @@ int yolo2_selftest_tr16(short *out, void *stream);
  *   wgrad plan out8 = {tile channels BC, tile filters BN, waves, taps paired, pixel ranges, XCD-local placement,
  *                      workgroups, direct store (no atomics)};                                      all -1 = first-layer kernel */
 int yolo2_debug_last_conv_plan(int *out8);
+/* measurement hook: launches an empty kernel (bench.py calibrates the overhead of its HIP-event brackets with it) */
+int yolo2_debug_noop(void *stream);
 /* test hook: tap-fused 3x3 implicit-GEMM variant on (default) / off for the calling process */
 int yolo2_debug_set_igemm_tap(int on);
 int yolo2_debug_last_wgrad_plan(int *out8);

@@ -30,6 +30,7 @@ SIGNATURES = {
     'yolo2_conv2d_bias_leaky': [_p, _p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _f, _i, _p],
     'yolo2_conv2d_dgrad_bn': [_p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f, _f, _p, _i, _p],
     'yolo2_bn_part_to_grads': [_p, _i, _p, _p, _p],
+    'yolo2_debug_noop': [_p],
     'yolo2_conv2d_wgrad': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep_batch': [_p, _i, _i, _i, _p],

@@ -239,6 +239,11 @@ def last_conv_plan():
     return dict(zip(CONV_PLAN_KEYS, list(out)))
 
 
+def noop():
+    """Empty kernel on the current stream (event-bracket calibration in bench.py)."""
+    call('yolo2_debug_noop', _stream())
+
+
 def set_igemm_tap(on):
     """Test hook: tap-fused 3x3 implicit-GEMM variant on / off (process-wide)."""
     _lib.load().yolo2_debug_set_igemm_tap(int(bool(on)))
