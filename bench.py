@@ -42,7 +42,7 @@ F32_MATRIX_PEAK_TFLOPS = 157.3
 # 1.00 on bn_leaky_kernel (profiles/r01_hbm_traffic_pmc_final.md: 99.1 MB fetched + 27.2 MB written per launch).  The counters
 # sit between L2 and the fabric: Infinity-Cache hits are included (the 3072-channel layer alone re-reads its filter slab from
 # the MALL 11 times: 0.8 GB).  Algorithmic bytes (every operand once): 31.9 MB, 40.4 GFLOP per launch.
-IGEMM_HBM_BYTES_PER_LAUNCH = 123.4e6      # profiles/r02_hbm_traffic_pmc.md: FETCH_SIZE x 1024 x 2 (94.4 MB) + WRITE_SIZE x 1024 (29.0 MB), 24 launches
+IGEMM_HBM_BYTES_PER_LAUNCH = 124.2e6      # profiles/r02_bench_roofline_check.txt: FETCH_SIZE x 1024 x 2 (95.0 MB) + WRITE_SIZE x 1024 (29.2 MB), 24 launches
 IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 31.9e6
 TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
 
