@@ -283,6 +283,30 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         const unsigned char *As = smem + c_stage * STAGE + (wm * TM * 32 + frow) * ROWB;
         const unsigned char *Bs = smem + c_stage * STAGE + (BM + wn * TN * 32 + frow) * ROWB;
         c_stage = (c_stage + 1 == NSTAGE) ? 0 : c_stage + 1;
+        // 128-byte rows, 8 waves of 32 x 64 (bf16): all twelve fragment reads of the K step are issued before its first MFMA (48 VGPRs)
+        // and the MFMAs wait with a falling lgkmcnt; left to itself hipcc issues read, wait, MFMA, read, wait, MFMA ... and every
+        // MFMA pair pays a full LDS latency (the tap-fused kernel below gained 15 % from the same change).
+        constexpr bool HOIST = sizeof(T) == 2 && CH == 8 && NW == 8 && BM == 128 && Y2_ABL == 0;
+        if constexpr (HOIST) {
+            constexpr int KK = BK / Mma<T>::KSTEP;
+            typename Mma<T>::Frag af[KK][TM], bf[KK][TN];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const int boff = ((kk * 2 + (lane >> 5)) ^ fsw) * 16;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = Mma<T>::mma(af[kk][i], bf[kk][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else
 #pragma unroll
         for (int kk = 0; kk < BK / Mma<T>::KSTEP; ++kk) {
             typename Mma<T>::Frag af[TM], bf[TN];
