@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     constexpr int XRPI = 1024 / XROWB, YRPI = 1024 / YROWB;           // pixel rows per DMA instruction
     constexpr int X_IT = BKP / XRPI / NW, Y_IT = BKP / YRPI / NW;     // DMA instructions per wave per tile
     constexpr int LOADS = X_IT + Y_IT;
-    constexpr int NSTAGE = 3;
+    constexpr int NSTAGE = BKPv == 64 ? 2 : 3;            // (64-pixel reduction tiles: two stages keep the ring at the 32-pixel variant's LDS footprint)
     constexpr int XBYTES = BKP * XROWB, STAGE = XBYTES + BKP * YROWB;
     constexpr int WGM = NW / 2;                        // waves arranged WGM x 2 over the (c, n) tile
     constexpr int TM = BC / WGM / 32, TN = BNN / 64;
@@ -480,7 +480,21 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     if (small) {
         Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 64, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
     } else {
-        Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 128, 128>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
+        // 64-pixel reduction tiles on a 2-stage ring (8 MFMAs per wave between barriers, same 64 KiB of LDS): pays when the launch gives
+        // a CU about one workgroup -- single-range grids of up to 1.5 blocks per CU (the 512 -> 1024 13x13 layers: 41.9 -> 36.6 us);
+        // with two or three workgroups per CU the 32-pixel / 3-stage form wins (conv18: 66.5 vs 73.1 us).  YOLO2_WGRAD_BKP64=0 / 1: never / always.
+        static const int bkp64 = getenv("YOLO2_WGRAD_BKP64") ? atoi(getenv("YOLO2_WGRAD_BKP64")) : -1;
+        bool use64 = bkp64 == 1;
+        if (bkp64 < 0 && dtype == YOLO2_BF16 && g_wgrad_variant == 0) {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            static int cached_cus = 0;
+            if (!cached_cus) cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : cus;
+            const WgradPlan pl = wgrad_plan(B * H * W, Cin, Cout, ksize, 128, 128, 32);
+            use64 = pl.ks == 1 && 2 * pl.blocks <= 3 * cached_cus;
+        }
+        if (use64 && dtype == YOLO2_BF16) launch_wgrad<bf16, 128, 128, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st);
+        else Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 128, 128>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
     }
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
