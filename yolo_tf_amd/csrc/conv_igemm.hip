@@ -37,8 +37,11 @@
 //     the tile's owner through sc1 (agent-coherent, fence-free) accesses -- see the SPLITK == 2 epilogue; long
 //     reductions take a 256x128 tile (8 waves of 64x64, 16 MFMAs per barrier).  Grids <= 128 tiles with a medium
 //     reduction slice the K loop over gridDim.y with f32 atomics + a finishing kernel (SPLITK == 1).
-//   * The epilogue can also emit the batch-norm partial sums of the stored outputs (yolo2_conv2d_bn) and apply
-//     bias + leaky ReLU (yolo2_conv2d_bias_leaky, BN-folded inference).
+//   * The epilogue can also emit the batch-norm partial sums of the stored outputs (yolo2_conv2d_bn), apply
+//     bias + leaky ReLU (yolo2_conv2d_bias_leaky, BN-folded inference), and -- for a data gradient whose output is the gradient of a
+//     batch-normalised producer layer -- reduce that layer's dgamma / dbeta sums from the tile image (yolo2_conv2d_dgrad_bn).
+//   * 3x3 layers with >= 1024 input channels on images up to 55 wide take conv3x3_tap_kernel (further down): one halo image per
+//     64-channel chunk serves all nine taps, software-pipelined K loop.
 //   * blockIdx -> tile: filter tile fastest (the blocks of XCD b%8 keep one filter slab in their L2), or,
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"

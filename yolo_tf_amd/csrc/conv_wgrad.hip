@@ -18,7 +18,9 @@
 // plain ds_read_b32, lanes along channels).
 // Image borders / SAME padding / tails: the X lane whose shifted pixel falls outside the image, and every
 // lane beyond the pixel range or channel count, uses an out-of-range buffer offset -> the DMA writes 0.
-// 3-stage LDS ring with counted vmcnt + raw s_barrier as in conv_igemm.hip.
+// 3-stage LDS ring with counted vmcnt + raw s_barrier as in conv_igemm.hip (64-pixel reduction tiles on a 2-stage ring when a launch gives a
+// CU about one workgroup).  The transpose reads are inline asm (the builtin drains the DMA ring: see common.h) with ONE address per
+// fragment row and the row step in the instruction's offset field.
 // (A 256 x 128 tile with 64-pixel reduction tiles -- 64 x 64 per wave, 144 KiB ring, one workgroup per CU -- was
 // measured 1.5-1.9x slower on the 13x13 / 26x26 stages: the per-DMA-piece border bookkeeping and the single resident
 // workgroup outweigh the halved LDS traffic; profiles/r01_wgrad_big_tile.txt.)
