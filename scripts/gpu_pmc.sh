@@ -2,6 +2,8 @@
 # SQ counters of the conv kernels (forward igemm + wgrad of 6 layers), with the MFMA-busy normalisation calibrated on a pure MFMA loop
 R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/gpurun_out/pmc; cd /tmp; export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc/p* $R/gpurun_out/pmc/cal
+mkdir -p $R/scripts/experiments/build
+[ -x $R/scripts/experiments/build/mfma_peak ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/scripts/experiments/mfma_peak.hip -o $R/scripts/experiments/build/mfma_peak 2>/dev/null
 timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES --kernel-trace --output-format csv -d $R/gpurun_out/pmc/cal -o r -- $R/scripts/experiments/build/mfma_peak > $R/gpurun_out/pmc/cal.log 2>&1
 python - <<PY | tee $R/gpurun_out/pmc/calibration.txt
 import csv, glob
