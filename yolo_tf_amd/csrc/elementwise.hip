@@ -1268,16 +1268,38 @@ extern "C" int yolo2_scale(float *x, long n, float scale, void *stream) {
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
-extern "C" int yolo2_zero_ranges(float *x, const long *ranges_host, int nranges, void *stream) {
-    Y2_CHECK_ARG(x && (nranges == 0 || ranges_host) && nranges >= 0);
-    for (int i = 0; i < nranges; ++i) {
-        const long a = ranges_host[2 * i], b = ranges_host[2 * i + 1];
-        Y2_CHECK_ARG(a >= 0 && b >= a);
-        if (b > a && hipMemsetAsync(x + a, 0, (size_t)(b - a) * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-            yolo2_set_error("yolo2_zero_ranges: memset failed");
-            return YOLO2_E_LAUNCH;
+// up to Y2_ZR_MAX ranges per launch, passed by value (one launch instead of one hipMemsetAsync node per range: 5 launches per training step)
+#define Y2_ZR_MAX 16
+struct Y2ZeroRanges { long a[Y2_ZR_MAX], b[Y2_ZR_MAX]; int n; };
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float *__restrict__ x, const Y2ZeroRanges zr) {
+    const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    for (int r = 0; r < zr.n; ++r) {
+        const long a = zr.a[r], b = zr.b[r];
+        const long a4 = (a + 3) & ~3L, b4 = b & ~3L;            // 16-byte body, scalar edges
+        if (a4 <= b4) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            for (long i = a4 / 4 + tid; i < b4 / 4; i += stride) reinterpret_cast<f32x4 *>(x)[i] = z;
+            for (long i = a + tid; i < a4; i += stride) x[i] = 0.f;
+            for (long i = b4 + tid; i < b; i += stride) x[i] = 0.f;
+        } else {
+            for (long i = a + tid; i < b; i += stride) x[i] = 0.f;
         }
     }
+}
+extern "C" int yolo2_zero_ranges(float *x, const long *ranges_host, int nranges, void *stream) {
+    Y2_CHECK_ARG(x && (nranges == 0 || ranges_host) && nranges >= 0 && ((uintptr_t)x & 15) == 0);
+    for (int i0 = 0; i0 < nranges; i0 += Y2_ZR_MAX) {
+        Y2ZeroRanges zr;
+        zr.n = 0;
+        long total = 0;
+        for (int i = i0; i < nranges && i < i0 + Y2_ZR_MAX; ++i) {
+            const long a = ranges_host[2 * i], b = ranges_host[2 * i + 1];
+            Y2_CHECK_ARG(a >= 0 && b >= a);
+            if (b > a) { zr.a[zr.n] = a; zr.b[zr.n] = b; ++zr.n; total += b - a; }
+        }
+        if (zr.n) zero_ranges_kernel<<<ew_grid(total / 4 + 1), 256, 0, (hipStream_t)stream>>>(x, zr);
+    }
+    Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
 extern "C" int yolo2_bn_fold(const float *W, const float *gamma, const float *beta, const float *moving_mean, const float *moving_var, float *Wf,

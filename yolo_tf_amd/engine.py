@@ -65,6 +65,7 @@ class Engine(object):
         self._filters_dirty = True
         self._zero_ranges = None
         self.reg_loss = torch.zeros(1, dtype=torch.float64, device=self.device)      # sum of the regularisation terms of the last backward
+        self._has_l2 = any(op.get('l2') for op in graph.ops)                         # (only the YOLO v1 family's fully connected layers)
         self.dropout_masks = None    # {op name: uint8 mask}: fixed keep masks (parity tests); None = drawn on the device per step
         self.dropout_seed = int(seed) + 1
         self._dropout_calls = 0
@@ -456,7 +457,8 @@ class Engine(object):
         reduced = set()
         inputs = set(self.graph.inputs.values())
         self._phase = 'dgrad'
-        self.reg_loss.zero_()
+        if self._has_l2:
+            self.reg_loss.zero_()
         main = torch.cuda.current_stream()
         side = self.side_stream if self.overlap_wgrad else None
         slot = 0
