@@ -311,7 +311,7 @@ def test_conv_dgrad_bn_fused_sums(ops, shape, fused, mode):
     plan = ops.last_conv_plan()
     assert pending == bool(plan['split'] & 0x100), (pending, plan)
     if mode == 'bf16':                     # (f32 tiles of some variants do not fit the LDS image: those run the two-step form)
-        assert pending == fused, (pending, plan)
+        assert pending == (fused and os.environ.get('YOLO2_FUSE_BN_BWD', '1') != '0'), (pending, plan)
     if pending:
         ops.bn_part_to_grads(part, Cin, dg, db)
     torch.cuda.synchronize()
