@@ -214,8 +214,8 @@ def cpu_nms_baseline(classes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100, help='timed steps (0.4 s of GPU time at the default: long enough for the clocks to settle; 20 / 100 / 300 steps measure the same rate within 1 %)')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='images per GPU (weak scaling)')
     ap.add_argument('--global-batch', type=int, default=0, help='fixed total batch split over the GPUs (strong scaling; BASELINE configs[2] = 64 on 8)')
     ap.add_argument('--names', type=int, default=20, choices=[20, 80])
