@@ -886,7 +886,7 @@ def yolo1_tiny_spec(classes, boxes_per_cell, cells):
     ops.append(('flatten',))
     for i, units in enumerate((256, 4096)):
         ops += [('fc', 'fc%d' % i, units, True, 0.001), ('dropout', 'dropout%d' % i, 0.5)]
-    ops.append(('fc', 'fc', cells * (classes + boxes_per_cell * 5), False, 0.001))
+    ops.append(('fc', 'fc', cells * (classes + boxes_per_cell * 5), False, 0.0))     # outside the regularised arg_scope (model/yolo/inference.py:62)
     return ops
 
 

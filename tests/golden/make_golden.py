@@ -12,31 +12,37 @@ Reference functions exercised:
     model/yolo/__init__.py:29-34    calc_cell_xy
     utils/preprocess.py:23-25       per_image_standardization
     parse_darknet_yolo2.py:34-48    transpose_weights, transpose_biases
-    model/yolo2/function.py:32-47   reorg known-answer image (the TF op itself cannot run; the
-                                    KAT's input and its asserted per-channel constants are stored)
+    model/yolo2/function.py:32-47   reorg known-answer image (the KAT's input and its asserted per-channel constants)
+and, executed under the NumPy-backed TensorFlow stand-in of tests/golden/tf_numpy_shim.py (which states what such a run
+pins -- everything the reference's Python decides -- and what it cannot: the arithmetic inside each elementary TF op):
+    model/yolo2/__init__.py:28-94   Model (every attribute) and Objectives (the four terms)       -> model.npz
+    model/yolo/__init__.py:37-100   the YOLO (v1) Model and Objectives                            -> model.npz
+    model/yolo2/function.py:22-47   reorg on a random tensor; the reference's own main() KAT run  -> model.npz
+    model/yolo2/inference.py:25-120 tiny / darknet / _tiny / _darknet: layer tables, variable names, concat order (topology.json)
+    model/yolo/inference.py:23-64   and the logits of seeded weights on a seeded image (network.npz; tests/golden/seeded.py)
 """
 import importlib.util
+import json
 import os
 import sys
 import types
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import seeded            # noqa: E402
+import tf_numpy_shim as shim   # noqa: E402
+
 REF = '/root/reference'
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def _stub_tf():
-    names = ['tensorflow', 'tensorflow.python', 'tensorflow.python.client',
-             'tensorflow.python.client.device_lib', 'tensorflow.contrib', 'tensorflow.contrib.slim',
-             'matplotlib', 'matplotlib.patches', 'matplotlib.pyplot']
+    shim.install()           # tensorflow, tensorflow.contrib.slim, tensorflow.python.client.device_lib: NumPy-backed stand-ins
+    names = ['matplotlib', 'matplotlib.patches', 'matplotlib.pyplot']
     for n in names:
         if n not in sys.modules:
             sys.modules[n] = types.ModuleType(n)
-    sys.modules['tensorflow'].contrib = sys.modules['tensorflow.contrib']
-    sys.modules['tensorflow.contrib'].slim = sys.modules['tensorflow.contrib.slim']
-    sys.modules['tensorflow.python'].client = sys.modules['tensorflow.python.client']
-    sys.modules['tensorflow.python.client'].device_lib = sys.modules['tensorflow.python.client.device_lib']
     sys.modules['matplotlib'].patches = sys.modules['matplotlib.patches']
     if not hasattr(np, 'int'):
         np.int = int
@@ -93,6 +99,11 @@ def make_nms(post):
     conf = rng.uniform(0, 0.5, (40, 5, 6)).astype(np.float32)
     mn, mx = boxes_from(rng.uniform(0, 13, (40, 5, 2)), rng.uniform(0, 4, (40, 5, 2)))
     nms_case(post, 'dense', conf, mn, mx, 0.3, 0.4, cases)
+    # 2b. the full-size dense stress case of SURVEY 8c(2): every one of 845 x 20 scores is a candidate (~70 s in the Python reference)
+    rng = np.random.RandomState(10)
+    conf = rng.uniform(0.3, 1.0, (169, 5, 20)).astype(np.float32)
+    mn, mx = boxes_from(rng.uniform(0, 13, (169, 5, 2)), rng.uniform(0.5, 5.5, (169, 5, 2)))
+    nms_case(post, 'dense845', conf, mn, mx, 0.3, 0.4, cases)
     # 3. clustered duplicates: 8 clusters of jittered boxes
     rng = np.random.RandomState(3)
     cen = np.repeat(rng.uniform(2, 11, (8, 2)), 20, 0) + rng.normal(0, 0.15, (160, 2))
@@ -194,6 +205,111 @@ def make_weights():
     print('weights.npz', len(cases), 'arrays')
 
 
+def _labels_for(ref_data, classes, cw, ch, batch, seed):
+    """Label tensors produced by the reference's own transform_labels for seeded boxes, stacked over the batch."""
+    rng = np.random.RandomState(seed)
+    per_image = []
+    for _ in range(batch):
+        k = rng.randint(1, 7)
+        cen = rng.uniform(0.05, 0.95, (k, 2))
+        wh = rng.uniform(0.05, 0.6, (k, 2))
+        coord = np.clip(np.concatenate([cen - wh / 2, cen + wh / 2], 1), 0, 1).astype(np.float32)
+        cls = rng.randint(0, classes, k).astype(np.int64)
+        per_image.append(ref_data.transform_labels(cls, coord, classes, cw, ch))
+    return [np.stack([p[i] for p in per_image]).astype(np.float32) for i in range(6)]
+
+
+MODEL_ATTRS = ('iou', 'offset_xy', 'wh', 'prob', 'areas', 'offset_xy_min', 'offset_xy_max', 'wh01', 'wh01_sqrt', 'coords', 'xy', 'xy_min', 'xy_max', 'conf')
+MODEL1_ATTRS = ('prob', 'iou', 'offset_xy', 'coords', 'wh', 'offset_xy_min', 'offset_xy_max', 'areas', 'xy', 'xy_min', 'xy_max', 'conf')
+LABEL_KEYS = ('mask', 'prob', 'coords', 'offset_xy_min', 'offset_xy_max', 'areas')
+
+
+def make_model(ref_yolo2, ref_yolo, ref_fn, ref_data):
+    """The reference's Model / Objectives classes and reorg, executed on seeded logits and on labels from its transform_labels."""
+    import tensorflow as tf
+    cases = {}
+    here = os.path.join(os.path.dirname(OUT), '..', 'config', 'yolo2', 'anchors')
+    for name, classes, tsv, ch, cw, batch, seed in (('voc13', 20, 'voc.tsv', 13, 13, 2, 31), ('coco_rect', 80, 'coco.tsv', 10, 19, 1, 32),
+                                                    ('voc_big_logits', 20, 'voc.tsv', 13, 13, 2, 33)):
+        shim.reset()
+        anchors = np.loadtxt(os.path.join(here, tsv), delimiter='\t', skiprows=1)          # float64, as pandas read_csv(...).values gives the reference
+        rng = np.random.RandomState(seed)
+        scale = 4.0 if name == 'voc_big_logits' else 1.0
+        net = (rng.standard_normal((batch, ch, cw, len(anchors) * (5 + classes))) * scale).astype(np.float32)
+        labels = _labels_for(ref_data, classes, cw, ch, batch, seed + 100)
+        model = ref_yolo2.Model(tf.constant(net), classes, anchors, training=False)
+        obj = ref_yolo2.Objectives(model, *[tf.constant(a) for a in labels])
+        cases[name + '/net'], cases[name + '/anchors'], cases[name + '/classes'] = net, anchors, np.int64(classes)
+        for k, v in zip(LABEL_KEYS, labels):
+            cases[name + '/labels/' + k] = v
+        for k in MODEL_ATTRS:
+            cases[name + '/model/' + k] = getattr(model, k).value
+        assert list(obj.keys()) == ['iou_best', 'iou_normal', 'coords', 'prob']
+        for k in obj:
+            cases[name + '/objectives/' + k] = obj[k].value
+    # YOLO (v1): per-cell class scores + boxes_per_cell x (iou, xy, sqrt wh)
+    for name, classes, boxes, ch, cw, batch, seed in (('v1_voc7', 20, 2, 7, 7, 2, 41), ('v1_rect', 4, 3, 3, 5, 1, 42)):
+        shim.reset()
+        rng = np.random.RandomState(seed)
+        tf.identity(tf.constant(np.zeros((batch, ch, cw, 8), np.float32)), name='yolo_tiny/conv')      # the tensor Model reads the grid size from (:39)
+        net = rng.uniform(-0.2, 1.0, (batch, ch * cw * (classes + boxes * 5))).astype(np.float32)
+        labels = _labels_for(ref_data, classes, cw, ch, batch, seed + 100)
+        model = ref_yolo.Model(tf.constant(net), 'yolo_tiny', classes, boxes, training=False)
+        obj = ref_yolo.Objectives(model, *[tf.constant(a) for a in labels])
+        cases[name + '/net'], cases[name + '/dims'] = net, np.array([classes, boxes, ch, cw], np.int64)
+        for k, v in zip(LABEL_KEYS, labels):
+            cases[name + '/labels/' + k] = v
+        for k in MODEL1_ATTRS:
+            cases[name + '/model/' + k] = getattr(model, k).value
+        for k in obj:
+            cases[name + '/objectives/' + k] = obj[k].value
+    # reorg: the reference's own known-answer main() must pass under the stand-in, then a random tensor
+    shim.reset()
+    ref_fn.main()
+    rng = np.random.RandomState(51)
+    x = rng.standard_normal((2, 26, 26, 8)).astype(np.float32)
+    cases['reorg/in'] = x
+    cases['reorg/out'] = ref_fn.reorg(tf.constant(x)).value
+    np.savez_compressed(os.path.join(OUT, 'model.npz'), **cases)
+    print('model.npz', len(cases), 'arrays')
+
+
+def make_topology(ref_inf2, ref_inf1):
+    """Layer tables + logits of the reference's inference functions (slim calls recorded and evaluated by the stand-in)."""
+    import tensorflow as tf
+    topo, cases = {}, {}
+    runs = (('yolo2_darknet', ref_inf2.darknet, 20, 5, 64), ('yolo2_tiny', ref_inf2.tiny, 20, 5, 64),
+            ('yolo2__darknet', ref_inf2._darknet, 20, 5, 64), ('yolo2__tiny', ref_inf2._tiny, 20, 5, 64),
+            ('yolo2_darknet_coco', ref_inf2.darknet, 80, 5, 64), ('yolo_tiny', ref_inf1.tiny, 20, 2, 128))
+    for key, fn, classes, boxes, size in runs:
+        rng = np.random.RandomState(61)
+        image = rng.standard_normal((2, size, size, 3)).astype(np.float32)
+        entry = {'function': fn.__name__, 'classes': classes, 'boxes': boxes, 'input': [2, size, size, 3]}
+        for training in (False, True):
+            if training and key in ('yolo_tiny', 'yolo2__darknet', 'yolo2__tiny', 'yolo2_darknet_coco'):
+                continue                              # (v1: dropout draws; the variants: same batch-norm code path as their base)
+            shim.reset(lambda name, shape, kind: seeded.value(name, shape, kind))
+            scope, net = fn(tf.constant(image), classes, boxes, training=training)
+            tag = key + ('/train' if training else '/infer')
+            cases[tag + '/logits'] = net.value
+            if training:
+                names = sorted(shim.UPDATES)
+                for n in (names[0], names[1], names[-2], names[-1]):
+                    cases[tag + '/update/' + n] = shim.UPDATES[n]
+            else:
+                entry['scope'] = scope
+                entry['layers'] = list(shim.LOG)
+                entry['variables'] = list(shim.VAR_INFO)
+                cases[key + '/image'] = image
+        consts = {k: list(getattr(ref_inf1 if key == 'yolo_tiny' else ref_inf2, k)) for k in dir(ref_inf1 if key == 'yolo_tiny' else ref_inf2) if k.endswith('_DOWNSAMPLING')}
+        entry['downsampling'] = consts
+        topo[key] = entry
+    with open(os.path.join(OUT, 'topology.json'), 'w') as f:
+        json.dump(topo, f, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, 'network.npz'), **cases)
+    print('topology.json', len(topo), 'networks; network.npz', len(cases), 'arrays')
+
+
 def main():
     _stub_tf()
     sys.path.insert(0, REF)
@@ -201,9 +317,21 @@ def main():
     pre = _load('utils/preprocess.py', 'ref_preprocess')
     import utils.data as ref_data          # noqa: E402  (reference package, stubbed TF)
     import model.yolo as ref_yolo          # noqa: E402
-    make_nms(post)
-    make_labels(ref_data, ref_yolo, pre)
-    make_weights()
+    import model.yolo2 as ref_yolo2        # noqa: E402
+    import model.yolo2.function as ref_fn  # noqa: E402
+    import model.yolo2.inference as ref_inf2   # noqa: E402
+    import model.yolo.inference as ref_inf1    # noqa: E402
+    only = sys.argv[1:]
+    if not only or 'nms' in only:
+        make_nms(post)
+    if not only or 'labels' in only:
+        make_labels(ref_data, ref_yolo, pre)
+    if not only or 'weights' in only:
+        make_weights()
+    if not only or 'model' in only:
+        make_model(ref_yolo2, ref_yolo, ref_fn, ref_data)
+    if not only or 'topology' in only:
+        make_topology(ref_inf2, ref_inf1)
 
 
 if __name__ == '__main__':

@@ -704,7 +704,7 @@ def test_head_decode_f32(ops, classes):
     assert int(flag.item()) != 0       # tf.check_numerics counterpart (detect.py:70)
 
 
-NMS_CASES = ['sparse20', 'sparse80', 'dense', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
+NMS_CASES = ['sparse20', 'sparse80', 'dense', 'dense845', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
 
 
 def _gpu_nms(ops, conf, mn, mx, thr, thr_iou):

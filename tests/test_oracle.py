@@ -24,7 +24,7 @@ def lab_g(golden_dir):
     return np.load(os.path.join(golden_dir, 'labels.npz'))
 
 
-NMS_CASES = ['sparse20', 'sparse80', 'dense', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
+NMS_CASES = ['sparse20', 'sparse80', 'dense', 'dense845', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
 
 
 def _nms_lib():

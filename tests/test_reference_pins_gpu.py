@@ -1,0 +1,155 @@
+"""The HIP path against fixtures produced by executing the reference's OWN source (tests/test_reference_pins.py explains how:
+tests/golden/make_golden.py runs model/yolo2/__init__.py Model + Objectives and model/yolo2/inference.py under a NumPy-backed
+TensorFlow stand-in).  No oracle in between: kernels and engine are compared with model.npz / network.npz directly, through
+the C ABI.  Tolerances: the north_star's 1e-4 relative for f32."""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import seeded   # noqa: E402
+
+from test_kernels_gpu import assert_close, dev, host, pad_channels, F32_RTOL   # noqa: E402
+from test_network_gpu import make_builder                                        # noqa: E402
+
+LABEL_KEYS = ('mask', 'prob', 'coords', 'offset_xy_min', 'offset_xy_max', 'areas')
+OBJECTIVE_KEYS = ('iou_best', 'iou_normal', 'coords', 'prob')
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from yolo_tf_amd import ops as _ops
+    _ops._lib.load()
+    return _ops
+
+
+@pytest.mark.parametrize('case', ['voc13', 'coco_rect', 'voc_big_logits'])
+def test_decode_and_loss_kernels_vs_reference_source(ops, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'model.npz'))
+    net, anchors, classes = g[case + '/net'], g[case + '/anchors'].astype(np.float32), int(g[case + '/classes'])
+    B, ch, cw, D = net.shape
+    A = len(anchors)
+    n = ch * cw * A
+    ld = ops.pad8(D)
+    logits = dev(pad_channels(net, ld))
+    z = lambda *s: torch.zeros(*s, device='cuda')
+    conf, mn, mx, flag = z(B * n * classes), z(B * n * 2), z(B * n * 2), torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.head_decode(logits, ld, dev(anchors), conf, mn, mx, flag, B, ch, cw, A, classes)
+    iou, prob, xy, wh = z(B * n), z(B * n * classes), z(B * n * 2), z(B * n * 2)
+    ops.head_decode_attrs(logits, ld, dev(anchors), iou, prob, xy, wh, B, ch, cw, A, classes)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    for name, t in (('conf', conf), ('xy_min', mn), ('xy_max', mx), ('iou', iou), ('prob', prob), ('xy', xy), ('wh', wh)):
+        ref = g['%s/model/%s' % (case, name)]
+        assert_close(host(t).reshape(ref.shape), ref, F32_RTOL, name)
+    labels = [g['%s/labels/%s' % (case, k)] for k in LABEL_KEYS]
+    objs = z(4)
+    ws = z(ops.loss_ws_floats(B, ch * cw, A))
+    dl = z(B * ch * cw * ld)
+    ops.loss(logits, ld, dev(anchors), [dev(l.reshape(B, ch * cw, -1)) for l in labels], [1., 1., 1., 1.], objs, dl, ws, B, ch, cw, A, classes)
+    torch.cuda.synchronize()
+    got = host(objs)
+    for i, k in enumerate(OBJECTIVE_KEYS):
+        ref = float(g['%s/objectives/%s' % (case, k)])
+        assert abs(got[i] - ref) <= F32_RTOL * abs(ref) + 1e-9, (k, got[i], ref)
+
+
+@pytest.mark.parametrize('case', ['v1_voc7', 'v1_rect'])
+def test_yolo1_decode_and_loss_kernels_vs_reference_source(ops, golden_dir, case):
+    g = np.load(os.path.join(golden_dir, 'model.npz'))
+    net = g[case + '/net']
+    classes, boxes, ch, cw = [int(v) for v in g[case + '/dims']]
+    B, width = net.shape
+    n = ch * cw * boxes
+    ld = ops.pad8(width)
+    logits = dev(pad_channels(net, ld)).reshape(-1)
+    z = lambda *s: torch.zeros(*s, device='cuda')
+    conf, mn, mx, flag = z(B * n * classes), z(B * n * 2), z(B * n * 2), torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.yolo1_head_decode(logits, ld, conf, mn, mx, flag, B, ch, cw, boxes, classes)
+    torch.cuda.synchronize()
+    for name, t in (('conf', conf), ('xy_min', mn), ('xy_max', mx)):
+        ref = g['%s/model/%s' % (case, name)]
+        ref = np.broadcast_to(ref, (B, ch * cw, boxes, ref.shape[-1]))
+        assert_close(host(t).reshape(ref.shape), ref, F32_RTOL, name)
+    labels = [g['%s/labels/%s' % (case, k)] for k in LABEL_KEYS]
+    objs, dnet = z(4), z(B * ld)
+    ws = z(ops.loss_ws_floats(B, ch * cw, boxes))
+    ops.yolo1_loss(logits, ld, [dev(l) for l in labels], [1., 1., 1., 1.], objs, dnet, ws, B, ch, cw, boxes, classes)
+    torch.cuda.synchronize()
+    got = host(objs)
+    for i, k in enumerate(OBJECTIVE_KEYS):
+        ref = float(g['%s/objectives/%s' % (case, k)])
+        assert abs(got[i] - ref) <= F32_RTOL * abs(ref) + 1e-9, (k, got[i], ref)
+
+
+def test_reorg_kernel_vs_reference_source(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'model.npz'))
+    x, ref = g['reorg/in'], g['reorg/out']
+    B, H, W, C = x.shape
+    out = torch.zeros(ref.size, device='cuda')
+    ops.reorg(dev(x), out, B, H, W, C, 4 * C)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out).reshape(ref.shape), ref)
+
+
+@pytest.mark.parametrize('key,inference,names', [('yolo2_darknet', 'darknet', 20), ('yolo2_tiny', 'tiny', 20), ('yolo2_darknet_coco', 'darknet', 80)])
+def test_engine_logits_vs_reference_source(golden_dir, key, inference, names):
+    """Engine forward (f32, moving-average BN) with name-seeded weights == the logits the reference's inference function produced for
+    the same weights and image: layer order, channel counts, passthrough tap, reorg, concat order, BN variable roles."""
+    from yolo_tf_amd.engine import Engine
+    with open(os.path.join(golden_dir, 'topology.json')) as f:
+        entry = json.load(f)[key]
+    g = np.load(os.path.join(golden_dir, 'network.npz'))
+    image = g[key + '/image']
+    B, size = image.shape[0], image.shape[1]
+    with tempfile.TemporaryDirectory() as d:
+        builder, _ = make_builder(inference, names, size, False, d)
+    for fold in ('1', '0'):
+        os.environ['YOLO2_FOLD_BN'] = fold
+        try:
+            e = Engine(builder.graph, B, 'f32', training=False)
+        finally:
+            os.environ.pop('YOLO2_FOLD_BN')
+        e.set_variables({v['name']: seeded.value(v['name'], v['shape'], v['kind']) for v in entry['variables']})
+        e.set_images(torch.from_numpy(image).cuda(), mode=2)
+        e.forward()
+        torch.cuda.synchronize()
+        out = e.output()
+        buf, ld = e.act[out]
+        got = buf[:B * out.h * out.w * ld].float().cpu().numpy().reshape(B, out.h, out.w, ld)[..., :out.c]
+        ref = g[key + '/infer/logits']
+        assert got.shape == ref.shape
+        assert_close(got, ref, 2e-4, 'logits (fold_bn=%s)' % fold)
+
+
+def test_engine_training_forward_vs_reference_source(golden_dir):
+    """Batch-statistics forward + moving-average updates of the first and last BN layers vs the reference function in training mode."""
+    from yolo_tf_amd.engine import Engine
+    key = 'yolo2_darknet'
+    with open(os.path.join(golden_dir, 'topology.json')) as f:
+        entry = json.load(f)[key]
+    g = np.load(os.path.join(golden_dir, 'network.npz'))
+    image = g[key + '/image']
+    B, size = image.shape[0], image.shape[1]
+    with tempfile.TemporaryDirectory() as d:
+        builder, _ = make_builder('darknet', 20, size, True, d)
+    e = Engine(builder.graph, B, 'f32', training=True)
+    e.set_variables({v['name']: seeded.value(v['name'], v['shape'], v['kind']) for v in entry['variables']})
+    e.set_images(torch.from_numpy(image).cuda(), mode=2)
+    e.forward()
+    torch.cuda.synchronize()
+    out = e.output()
+    buf, ld = e.act[out]
+    got = buf[:B * out.h * out.w * ld].float().cpu().numpy().reshape(B, out.h, out.w, ld)[..., :out.c]
+    assert_close(got, g[key + '/train/logits'], 5e-4, 'training-mode logits')     # 2x2 cells x batch 2 = 8 samples per channel in the last stages
+    var = e.get_variables()
+    for k in [f for f in g.files if f.startswith(key + '/train/update/')]:
+        name = k[len(key + '/train/update/'):]
+        assert np.allclose(var[name], g[k], rtol=1e-4, atol=1e-6), name

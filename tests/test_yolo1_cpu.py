@@ -97,7 +97,7 @@ def test_yolo1_oracle_matches_torch_autograd():
              'coords': (mb[..., None] * (coords - tcoords) ** 2).sum() / cnt, 'prob': (mask[..., None] * (prob - tprob) ** 2).sum() / cnt}
     for k in terms:
         assert abs(float(terms[k].detach()) - float(obj[k])) <= 1e-12 * max(1.0, abs(float(obj[k]))), k
-    regt = sum(0.001 * (tp[op[1] + '/weights'] ** 2).sum() / 2 for op in spec if op[0] == 'fc')
+    regt = sum(op[4] * (tp[op[1] + '/weights'] ** 2).sum() / 2 for op in spec if op[0] == 'fc')        # fc0, fc1: 0.001; the output layer: none (topology.json)
     (sum(HP[k] * terms[k] for k in terms) + regt).backward()
     for k in g:
         assert np.allclose(tp[k].grad.numpy(), g[k], rtol=1e-8, atol=1e-12), k

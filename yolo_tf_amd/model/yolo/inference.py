@@ -3,7 +3,8 @@
 
 ``tiny``: nine 3x3 convolutions WITH biases and leaky_relu (no batch norm: slim.layers.conv2d without a normalizer_fn), 2x2 max
 pools after the first six (448 -> 7), flatten in (h, w, c) order, fully connected 256 and 4096 (leaky_relu, dropout 0.5 in
-training, l2 regulariser 0.001 on the weights) and a linear fully connected output of cells * (classes + boxes_per_cell * 5).
+training, l2 regulariser 0.001 on the weights) and a linear, un-regularised fully connected output of cells * (classes + boxes_per_cell * 5)
+(pinned by tests/golden/topology.json, recorded from the reference's own function).
 Variable scopes ``yolo_tiny/conv<i>/{weights,biases}``, ``yolo_tiny/fc<i>/...``, ``yolo_tiny/fc/...`` as in the reference."""
 from ... import graph as G
 
@@ -24,8 +25,8 @@ def tiny(net, classes, boxes_per_cell, training=False):
         net = G.fully_connected(net, units, scope='%s/fc%d' % (scope, index), weights_regularizer=0.001)
         net = G.dropout(net, 0.5, is_training=training, scope='%s/dropout%d' % (scope, index))
         index += 1
-    net = G.fully_connected(net, cell_width * cell_height * (classes + boxes_per_cell * 5), scope='%s/fc' % scope, activation=False,
-                            weights_regularizer=0.001)
+    # the output layer sits OUTSIDE the arg_scope that carries the regulariser (reference :62): no L2 term on its weights
+    net = G.fully_connected(net, cell_width * cell_height * (classes + boxes_per_cell * 5), scope='%s/fc' % scope, activation=False)
     return scope, net
 
 
