@@ -159,6 +159,42 @@ int yolo2_conv2d_bn(const void *P, const void *F, void *O, float *ws, size_t ws_
 int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int C, float *mean, float *var, float *moving_mean,
                       float *moving_var, double decay, void *stream);
 
+/* ---- Consumers that finalise the partial rows themselves (one launch instead of finalize + apply): slim.batch_norm's
+ * tf.nn.moments + assign_moving_average + normalisation (model/yolo2/inference.py:62-66) and the dgamma / dbeta + dY of its gradient
+ * (train.py:123-129), fed by the partial rows a producer left behind: yolo2_conv2d_bn / yolo2_conv2d_dgrad_bn (bn_part layout
+ * [2][YOLO2_BN_PART_ROWS][C]) or a *_reduce_part call ([2][rows][C] in its ws).  `rows` = how many partial rows the producer used:
+ * yolo2_last_bn_part_rows() right after the producing call on the same host thread (a producer wraps its tiles around few rows when
+ * it has many, so that this prologue stays short), or *rows of the reduce_part call.  yolo2_bn_fin_supported(rows, C, dtype) says
+ * whether the shape qualifies (C / (16 / elem size) a power of two; rows x channel-slice small enough that a per-workgroup
+ * prologue beats a separate finalisation launch); otherwise use yolo2_bn_finalize / yolo2_bn_part_to_grads / the plain pairs.
+ * The rows are only READ here.  zero / zero_floats (multiple of 4, 16-byte aligned; may be NULL / 0): a float range this launch
+ * clears on the side -- the engine keeps two partial buffers and has each consumer clear the one its predecessor finished with, so
+ * every producer finds zero rows without a memset launch.  Results equal the two-launch forms up to f64 summation order. */
+int yolo2_last_bn_part_rows(void);
+int yolo2_bn_fin_supported(int rows, int C, int dtype);
+int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var, float *moving_mean,
+                       float *moving_var, double decay, const float *gamma, const float *beta, void *A, long M, int C, int lda,
+                       float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream);
+int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var,
+                            float *moving_mean, float *moving_var, double decay, const float *gamma, const float *beta, void *P,
+                            unsigned char *idx, int B, int H, int W, int C, int ldp, float eps, float alpha, float *zero,
+                            long zero_floats, int dtype, void *stream);
+/* part: [2][rows][C] with plane_stride floats between the two planes (YOLO2_BN_PART_ROWS * C for bn_part, rows * C for a ws) */
+int yolo2_bn_leaky_bwd_apply_fin(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
+                                 const float *beta, const float *part, int rows, long plane_stride, float *dgamma, float *dbeta,
+                                 void *dY, long M, int C, float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream);
+int yolo2_bn_leaky_pool_bwd_apply_fin(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean,
+                                      const float *var, const float *gamma, const float *beta, const float *part, int rows,
+                                      long plane_stride, float *dgamma, float *dbeta, void *dY, int B, int H, int W, int C, float eps,
+                                      float alpha, float *zero, long zero_floats, int dtype, void *stream);
+/* pass 1 of the BN + leaky backward alone: partial rows [2][*rows][C] (f32) left in ws for a *_bwd_apply_fin call */
+int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
+                                   const float *beta, double *ws, int *rows, int rows_limit, long M, int C, float eps, float alpha,
+                                   int dtype, void *stream);
+int yolo2_bn_leaky_pool_bwd_reduce_part(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean,
+                                        const float *var, const float *gamma, const float *beta, double *ws, int *rows,
+                                        int rows_limit, int B, int H, int W, int C, float eps, float alpha, int dtype, void *stream);
+
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
 /* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1025*C doubles of scratch

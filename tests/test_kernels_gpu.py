@@ -530,6 +530,116 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
     assert_close(host(mv), R.bn_ema(np.ones(C, np.float32), var_r), 1e-5, 'ema var')
 
 
+def _host_partials(vals0, vals1, rows, C, plane_rows, rng, poison):
+    """[2][plane_rows][C] f32 partial rows: the M samples of each channel dealt to ``rows`` groups at random (what a producer's tiles
+    leave behind); rows >= ``rows`` hold NaN when ``poison`` (a consumer must not read them)."""
+    M = vals0.shape[0]
+    grp = rng.randint(0, rows, M)
+    part = np.full((2, plane_rows, C), np.nan if poison else 0.0, np.float32)
+    part[:, :rows] = 0
+    np.add.at(part[0], grp, vals0.astype(np.float32))
+    np.add.at(part[1], grp, vals1.astype(np.float32))
+    return part
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape,rows', [((2, 26, 26, 32), 256), ((4, 13, 13, 1024), 44), ((1, 52, 52, 64), 128), ((2, 26, 26, 512), 16), ((3, 8, 6, 8), 5),
+                                        ((2, 14, 14, 256), 64)])
+def test_bn_consumers_with_folded_finalisation_vs_oracle(ops, shape, rows, mode):
+    """yolo2_bn_leaky_fin / _pool_fin / _bwd_apply_fin / _pool_bwd_apply_fin: the kernels that sum the partial rows in their own prologue,
+    against the ORACLE (moments, moving averages, BN + leaky, pool, dgamma / dbeta, dY), plus the side clearing of another buffer."""
+    B, H, W, C = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rtol = F32_RTOL if mode == 'f32' else BF16_RTOL
+    rng = np.random.RandomState(C + rows)
+    y = (rng.randn(B, H, W, C) * 1.5 + rng.randn(C)).astype(np.float32)
+    da = rng.randn(B, H, W, C).astype(np.float32)
+    gamma = (rng.rand(C) + 0.5).astype(np.float32)
+    beta = (rng.randn(C) * 0.2).astype(np.float32)
+    shift = (rng.randn(C) * 0.3).astype(np.float32)
+    if mode == 'bf16':
+        y, da = bf16_round(y), bf16_round(da)
+    M = B * H * W
+    assert ops.bn_fin_supported(rows, C, tdtype)
+    mean_r, var_r = R.bn_moments(y)
+    z = R.bn_apply(y, mean_r, var_r, gamma, beta)
+    a_r = R.leaky_relu(z)
+    d = y.reshape(M, C) - shift
+    part = _host_partials(d, d * d, rows, C, 256, rng, poison=True)
+    yd, g, b_ = dev(y, tdtype), dev(gamma), dev(beta)
+    mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    lda = C + 16
+    A = torch.zeros(M * lda, dtype=tdtype, device='cuda')
+    other = torch.ones(4096, device='cuda')
+    ops.bn_leaky_fin(yd, dev(part), rows, dev(shift), mean, var, mm, mv, 0.999, g, b_, A, M, C, lda, 1e-5, 0.1, other, 1024)
+    torch.cuda.synchronize()
+    assert_close(host(mean), mean_r, 1e-5, 'mean')
+    assert_close(host(var), var_r, 2e-5, 'var')
+    assert_close(host(mm), R.bn_ema(np.zeros(C, np.float32), mean_r), 1e-5, 'ema mean')
+    assert_close(host(mv), R.bn_ema(np.ones(C, np.float32), var_r), 2e-5, 'ema var')
+    a = host(A).reshape(M, lda)
+    assert np.all(a[:, C:] == 0)
+    assert_close(a[:, :C].reshape(shape), a_r, rtol, 'bn_leaky_fin')
+    o = host(other)
+    assert np.all(o[:1024] == 0) and np.all(o[1024:] == 1)
+    # backward: partial rows of sum(g * xhat), sum(g) with g = dA * leaky'(z), in a compact [2][rows][C] workspace
+    dz = R.leaky_relu_grad(z, da)
+    dy_r, dg_r, db_r = R.bn_train_bwd(y, mean_r, var_r, gamma, dz)
+    inv = 1.0 / np.sqrt(var_r + np.float32(1e-5))
+    xhat = ((y - mean_r) * inv).reshape(M, C)
+    bpart = _host_partials(dz.reshape(M, C) * xhat, dz.reshape(M, C), rows, C, rows, rng, poison=False)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dY = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky_bwd_apply_fin(dev(da, tdtype), C, yd, dev(mean_r), dev(var_r), g, b_, dev(bpart), rows, rows * C, dg, db, dY, M, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert_close(host(dg), dg_r, max(rtol, 2e-4), 'dgamma')
+    assert_close(host(db), db_r, max(rtol, 2e-4), 'dbeta')
+    assert_close(host(dY).reshape(shape), dy_r, max(rtol, 2e-4), 'dY (bwd_apply_fin)')
+    limit = ops.bn_fin_rows_limit(C, tdtype)
+    ws = torch.zeros(1026 * C + 64, dtype=torch.float64, device='cuda')
+    r3 = ops.bn_leaky_bwd_reduce_part(dev(da, tdtype), C, yd, mean, var, g, b_, ws, limit, M, C, 1e-5, 0.1)
+    dg3, db3 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dy3 = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky_bwd_apply_fin(dev(da, tdtype), C, yd, mean, var, g, b_, ws, r3, r3 * C, dg3, db3, dy3, M, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert_close(host(dg3), dg_r, max(rtol, 2e-4), 'dgamma (reduce_part)')
+    assert_close(host(dy3).reshape(shape), dy_r, max(rtol, 2e-4), 'dY (reduce_part)')
+    if H % 2 or W % 2:
+        return
+    # pooled forward: equals the pool of the rounded activation the plain form stores (first-max routing checked against yolo2_maxpool_fwd elsewhere)
+    MP = B * (H // 2) * (W // 2)
+    P = torch.zeros(MP * C, dtype=tdtype, device='cuda')
+    idx = torch.full((MP * C,), 9, dtype=torch.uint8, device='cuda')
+    mean2, var2 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_leaky_pool_fin(yd, dev(part), rows, dev(shift), mean2, var2, None, None, 0.999, g, b_, P, idx, B, H, W, C, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(mean2, mean) and torch.equal(var2, var)
+    a_st = bf16_round(a_r) if mode == 'bf16' else a_r
+    p_r = R.max_pool(a_st, 2)
+    assert_close(host(P).reshape(p_r.shape), p_r, rtol, 'bn_leaky_pool_fin')
+    assert int(idx.max()) <= 3
+    # pooled backward through the device reduction (reduce_part leaves [2][rows][C]) == the plain pooled pair
+    dp = rng.randn(B, H // 2, W // 2, C).astype(np.float32)
+    if mode == 'bf16':
+        dp = bf16_round(dp)
+    dpd = dev(dp, tdtype)
+    dg_ref, db_ref = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ops.bn_leaky_pool_bwd_reduce(dpd, C, idx, yd, mean, var, g, b_, dg_ref, db_ref, ws, B, H, W, C, 1e-5, 0.1)
+    dy_ref = torch.zeros(M * C, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply(dpd, C, idx, yd, mean, var, g, b_, dg_ref, db_ref, dy_ref, B, H, W, C, 1e-5, 0.1)
+    r2 = ops.bn_leaky_pool_bwd_reduce_part(dpd, C, idx, yd, mean, var, g, b_, ws, limit, B, H, W, C, 1e-5, 0.1)
+    assert 1 <= r2 <= limit
+    dg2, db2 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dy2 = torch.full((M * C,), 7.0, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply_fin(dpd, C, idx, yd, mean, var, g, b_, ws, r2, r2 * C, dg2, db2, dy2, B, H, W, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert_close(host(dg2), host(dg_ref), 2e-5, 'pooled dgamma')
+    assert_close(host(db2), host(db_ref), 2e-5, 'pooled dbeta')
+    assert_close(host(dy2), host(dy_ref), 1e-5 if mode == 'f32' else 8e-3, 'pooled dY')
+
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('stride,shape', [(2, (2, 8, 12, 16)), (2, (1, 26, 26, 512)), (1, (2, 13, 13, 64)), (1, (1, 5, 3, 8))])
 def test_maxpool(ops, stride, shape, mode):

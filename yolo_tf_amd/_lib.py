@@ -36,6 +36,12 @@ SIGNATURES = {
     'yolo2_filter_prep_batch': [_p, _i, _i, _i, _p],
     'yolo2_conv2d_bn': [_p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
     'yolo2_bn_finalize': [_p, _p, _l, _i, _p, _p, _p, _p, ctypes.c_double, _p],
+    'yolo2_bn_leaky_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _l, _i, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_bn_leaky_pool_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_bn_leaky_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _l, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_bn_leaky_pool_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_bn_leaky_bwd_reduce_part': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _f, _f, _i, _p],
+    'yolo2_bn_leaky_pool_bwd_reduce_part': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_reduce': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
@@ -87,6 +93,8 @@ QUERIES = {
     'yolo2_crc32c': (ctypes.c_uint32, [_p, ctypes.c_size_t, ctypes.c_uint32]),
     'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
     'yolo2_debug_set_wgrad_variant': (None, [_i]),
+    'yolo2_last_bn_part_rows': (_i, []),
+    'yolo2_bn_fin_supported': (_i, [_i, _i, _i]),
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),

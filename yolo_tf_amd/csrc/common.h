@@ -62,7 +62,7 @@ int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H,
 #define Y2_BN_PART_ROWS YOLO2_BN_PART_ROWS
 // the 2 x Y2_BN_PART_ROWS partial rows of a fused BN-backward data gradient -> dgamma (plane 0), dbeta (plane 1); rows zeroed again
 int y2_bn_part_to_grads(float *part, int C, float *dgamma, float *dbeta, hipStream_t st);
-int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st);
+int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st, int *rows_used = nullptr);
 
 #define Y2_CHECK_ARG(cond)                                                          \
     do {                                                                            \

@@ -91,6 +91,10 @@ struct Y2BnBwd {
     const void *Y;      // pre-normalisation output of the producer layer, [M][Nf] (pixel stride = Nf)
     const float *mean, *var, *gamma, *beta;
     float eps, alpha;
+    // bits cleared from the partial-row index mask (Y2_BN_PART_ROWS - 1): grids with more (pixel tile, wave row) pairs than rows wrap
+    // around R = 256 >> popcount(stat_mask_inv) rows, chosen by the host so that the consumer that finalises the rows in its prologue
+    // (yolo2_bn_leaky_fin & co.) reads few of them while same-address atomic adds stay rare (y2_stat_rows below).  0 = all 256 rows.
+    int stat_mask_inv;
 };
 
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32) {
-                    const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                     float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
                     if (stats_unique) { *p1 = s1; *p2 = s2; }
                     else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32 && n_ok && !(Y2_ABL & 2)) {
-                    const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                     float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
                     if (stats_unique) { *p1 = s1; *p2 = s2; }      // one writer per (row, filter): a store into the zeroed row
                     else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                 }
             const int nb = n0 + wn * TN * 32 + lane * VEC;
             if (lane < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                 float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 if (lane < 32 && n_ok) {
-                    const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                     float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
                     if (stats_unique) { *p1 = s1; *p2 = s2; }
                     else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
@@ -1016,7 +1020,7 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
                 }
             const int nb = n0 + wn * TN * 32 + lane * VEC;
             if (lane < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm) & (Y2_BN_PART_ROWS - 1);
+                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                 float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -1113,22 +1117,40 @@ static int choose_ksplit(int tiles, int nk, int target) {
 // the plan of the calling thread's most recent launch (yolo2_debug_last_conv_plan): tests assert that the variant they
 // mean to check is the one that ran, since the choice is shape-driven
 static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Partial rows a statistics-producing launch touches (yolo2_last_bn_part_rows): what the consumer's prologue has to sum.  Up to
+// Y2_BN_PART_ROWS (pixel tile, wave row) pairs get a row each (plain stores, one writer per element); larger grids wrap around
+// R rows with f32 atomic adds, R chosen for <= ~170 adds per address (the 104x104 layer; 20-90 elsewhere) and <= 128 rows to read.
+static thread_local int g_last_stat_rows = Y2_BN_PART_ROWS;
+static int y2_stat_rows(long wave_rows) {
+    if (wave_rows <= Y2_BN_PART_ROWS) return (int)wave_rows;
+    int r = 16;
+    while (r < 128 && (long)r * 128 < wave_rows) r <<= 1;
+    return r;
+}
+static Y2BnBwd y2_with_stat_rows(Y2BnBwd bz, long wave_rows) {
+    const int r = y2_stat_rows(wave_rows);
+    g_last_stat_rows = r;
+    bz.stat_mask_inv = wave_rows <= Y2_BN_PART_ROWS ? 0 : (Y2_BN_PART_ROWS - 1) ^ (r - 1);
+    return bz;
+}
+extern "C" int yolo2_last_bn_part_rows(void) { return g_last_stat_rows; }
 #define Y2_IGEMM_ARGS (const T *)P, p_bytes, (const T *)F, f_bytes, bias, (T *)O, ws, H, W, Cp, ldp, Nf, ldo, M, NT, remap, bn_shift
 #define Y2_IGEMM_BM(BMv, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)                                        \
     do {                                                                                                           \
         const dim3 g_ = (gridv);                                                                                   \
         const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
         for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
+        const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)cdiv(M, BMv) * (NWv / WGNv));                              \
         if (!bz.Y)                                                                                                 \
             conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
-                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz);                                      \
+                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz_);                                     \
         else if (SPLITv != 1 && !CTv && wide_store && igemm_wide_fits<T, BMv, BNv, WGNv, NSv, CHv, NWv>())         \
             conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, (SPLITv == 1 ? 0 : SPLITv), false, CHv, NWv, BMv, true><<<g_, NWv * 64, 0, st>>>( \
-                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz);                                      \
+                Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz_);                                     \
         else {      /* this variant has no on-chip tile image to reduce from: the caller runs the two-step form */ \
             *stats_done = false;                                                                                   \
             conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
-                Y2_IGEMM_ARGS, nullptr, sk_flags, act_alpha, wide_store, Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}); \
+                Y2_IGEMM_ARGS, nullptr, sk_flags, act_alpha, wide_store, Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0}); \
         }                                                                                                          \
     } while (0)
 #define Y2_IGEMM(BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv) Y2_IGEMM_BM(128, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, gridv)
@@ -1168,7 +1190,7 @@ extern "C" int yolo2_debug_set_igemm_tap(int on) {
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
                        int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done, float act_alpha,
-                       const Y2BnBwd bz = Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f}) {
+                       const Y2BnBwd bz = Y2BnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0}) {
     const int M = B * H * W;
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
@@ -1204,9 +1226,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             (sk_flags = stream_flags()) != nullptr) {
             const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 9, 2, tu.cus, 1};      // "stages" 9: nine taps per halo image
             for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
+            const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4);
 #define Y2T_LAUNCH(BWDv, HRv, NSBv)                                                                                                      \
             conv3x3_tap_kernel<BWDv, HRv, NSBv><<<dim3(tu.cus), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
-                                                                              H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz)
+                                                                              H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_)
             if (W <= 27) { if (bz.Y) Y2T_LAUNCH(true, 312, 5); else Y2T_LAUNCH(false, 312, 5); }
             else { if (bz.Y) Y2T_LAUNCH(true, 368, 4); else Y2T_LAUNCH(false, 368, 4); }
 #undef Y2T_LAUNCH
@@ -1302,6 +1325,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
         for (int i = 0; i < 8; ++i) g_last_plan[i] = -1;      // direct first-layer kernel (conv_first.hip)
+        g_last_stat_rows = Y2_BN_PART_ROWS;
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
@@ -1331,7 +1355,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     if (rc) { yolo2_set_error("%s: workspace memset failed", fn); return YOLO2_E_LAUNCH; }
     Y2_CHECK_LAUNCH();
     if (bn_part && !stats_done)       // K-sliced path: statistics from a pass over the finished output
-        return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream);
+        return y2_colsum_into(O, ldo, (long)B * H * W, Nf, bn_shift, bn_part, dtype, (hipStream_t)stream, &g_last_stat_rows);
     return YOLO2_OK;
 }
 
@@ -1377,7 +1401,7 @@ extern "C" int yolo2_conv2d_dgrad_bn(const void *dY, const void *F, void *dX, fl
         yolo2_set_error("yolo2_conv2d_dgrad_bn: argument check failed: a producer-layer pointer is NULL");
         return YOLO2_E_ARG;
     }
-    const Y2BnBwd bz{Yprev, mean, var, gamma, beta, eps, alpha};
+    const Y2BnBwd bz{Yprev, mean, var, gamma, beta, eps, alpha, 0};
     return conv2d_impl(dY, F, nullptr, dX, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, dtype, stream, "yolo2_conv2d_dgrad_bn", nullptr, bn_part, 1.0f,
                        &bz, dgamma, dbeta, red_ws, pending);
 }

@@ -366,11 +366,12 @@ static int colsum_grid(long M, int C, int vec) {
 
 // Fallback producer of the convolution epilogue's partial format ([2][Y2_BN_PART_ROWS][C], zero on entry): used for the
 // layers whose convolution cannot produce the sums itself (first-layer direct kernel, K-sliced grids).
-int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st) {
+int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, float *part, int dtype, hipStream_t st, int *rows_used) {
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ld == C);
     int nb = colsum_grid(M, C, vec);
     if (nb > Y2_BN_PART_ROWS) nb = Y2_BN_PART_ROWS;
+    if (rows_used) *rows_used = nb;
     Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 2><<<nb, 256, 0, st>>>((const T *)Y, ld, M, C, part, shift, Y2_BN_PART_ROWS));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
@@ -826,6 +827,264 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_apply_kernel(const T *__restr
             }
             st16(dY + off + koff[k], o);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Consumers that finalise the partial rows themselves (round 3): the 36 bn_finalize / 7 reduce_finalize launches of a training
+// step were ~5 us each (a 16-workgroup kernel is all latency) plus a kernel boundary.  Here the kernel that NEEDS the batch
+// moments (BN apply) or dgamma / dbeta (BN backward apply) sums the partial rows of its own channels in its prologue.
+// Mapping: a workgroup owns ONE channel slice (blockIdx.y: up to 16 lanes x 16 bytes = 128 bf16 / 64 f32 channels) and strides
+// over pixel rows (blockIdx.x), so its prologue reads rows x slice x 2 floats (L2-resident: the producer just wrote them) instead
+// of rows x C x 2; the 256 threads split the rows, accumulate in f64, and meet in LDS.  The workgroups with blockIdx.x == 0 store
+// mean / var (+ moving averages) or dgamma / dbeta for their slice.  Rows are read-only here: a buffer that needs to be zero for
+// its next producer is cleared by the NEXT consumer kernel, which works on the other buffer of a pair (zero / zero_vec4 arguments).
+// ------------------------------------------------------------------------------------------
+struct SliceMap {   // 256 threads = rpb rows x lpr lanes; lane -> 16-byte channel group cg of slice blockIdx.y
+    int lpr, rpb, lane, row, cg, cs, c0;
+    __device__ SliceMap(int C, int vec) {
+        const int tpr = C / vec;
+        lpr = tpr < 16 ? tpr : 16;
+        rpb = 256 / lpr;
+        lane = threadIdx.x % lpr;
+        row = threadIdx.x / lpr;
+        cg = blockIdx.y * lpr + lane;
+        cs = lpr * vec;                  // channels of the slice (<= 128)
+        c0 = blockIdx.y * cs;
+    }
+};
+#define Y2_SLICE_MAX 128
+
+// sums[k][c] = sum over rows of part[k * plane + row * C + c0 + c], c < cs (f64); ends with a barrier.  A thread owns four adjacent
+// channels (one 16-byte load per row and plane) and every (256 / (cs / 4))-th row, so even a 128-channel slice has eight row groups
+// working in parallel: the prologue is a dependent chain in front of the whole workgroup and its length is what the fold pays.
+__device__ __forceinline__ void slice_partial_sums(const float *__restrict__ part, int rows, long plane, int C, const SliceMap &sm,
+                                                   double (*sums)[Y2_SLICE_MAX]) {
+    __shared__ double red[2][256 * 4];
+    const int q = sm.cs >> 2;                               // lanes per row (cs >= 8 for bf16, >= 4 for f32: q >= 1)
+    const int l4 = threadIdx.x % q, g = threadIdx.x / q, ng = 256 / q;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float *p = part + (long)k * plane + sm.c0 + l4 * 4;
+        double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
+        int r = g;
+        for (; r + ng < rows; r += 2 * ng) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (long)r * C), b = *reinterpret_cast<const f32x4 *>(p + (long)(r + ng) * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += (double)a[j]; t[j] += (double)b[j]; }
+        }
+        if (r < rows) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (long)r * C);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += (double)a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[k][g * sm.cs + l4 * 4 + j] = s[j] + t[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < sm.cs) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < ng; ++j) a += red[k][j * sm.cs + threadIdx.x];
+            sums[k][threadIdx.x] = a;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void grid_zero(float *__restrict__ zero, long zero_vec4) {
+    if (!zero) return;
+    const long nthreads = (long)gridDim.x * gridDim.y * 256;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < zero_vec4; i += nthreads) reinterpret_cast<f32x4 *>(zero)[i] = z;
+}
+
+// forward: batch moments from the partial rows (same arithmetic as bn_finalize_kernel<0>) + BN apply + leaky (+ 2x2 max pool)
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__ Y, const float *__restrict__ part, int rows, const float *__restrict__ shift,
+                                                           long Mstat, float *__restrict__ mean_out, float *__restrict__ var_out, float *__restrict__ mm,
+                                                           float *__restrict__ mv, float omd, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           T *__restrict__ A, unsigned char *__restrict__ idx, int B, int H, int W, int C, int lda, float eps,
+                                                           float alpha, float *__restrict__ zero, long zero_vec4) {
+    constexpr int N = Vec16<T>::N;
+    const SliceMap sm(C, N);
+    __shared__ double sums[2][Y2_SLICE_MAX];
+    __shared__ float cst[3][Y2_SLICE_MAX];
+    // the first pixel row's data is requested BEFORE the prologue: its HBM latency runs under the partial-row reduction
+    const PoolRow pr(H, W, C);
+    const long ML = POOL ? (long)B * pr.OH * pr.OW : (long)B * H * W;
+    const long step = (long)gridDim.x * sm.rpb;
+    long r = (long)blockIdx.x * sm.rpb + sm.row;
+    Vec16<T> v[POOL ? 4 : 1];
+    if (r < ML) {
+        if (POOL) {
+            const T *src = Y + pr.base(r) + sm.cg * N;
+            v[0] = ld16(src);
+            v[POOL ? 1 : 0] = ld16(src + C);
+            v[POOL ? 2 : 0] = ld16(src + (long)W * C);
+            v[POOL ? 3 : 0] = ld16(src + (long)W * C + C);
+        } else v[0] = ld16(Y + r * C + sm.cg * N);
+    }
+    slice_partial_sums(part, rows, (long)Y2_BN_PART_ROWS * C, C, sm, sums);
+    if (threadIdx.x < sm.cs) {
+        const int c = sm.c0 + threadIdx.x;
+        const double dm = sums[0][threadIdx.x] / (double)Mstat;
+        const double var = sums[1][threadIdx.x] / (double)Mstat - dm * dm;
+        const float fm = (float)((double)shift[c] + dm), fv = (float)(var > 0.0 ? var : 0.0);
+        cst[0][threadIdx.x] = fm;
+        cst[1][threadIdx.x] = (1.0f / sqrtf(fv + eps)) * gamma[c];
+        cst[2][threadIdx.x] = beta[c];
+        if (blockIdx.x == 0) {
+            mean_out[c] = fm;
+            var_out[c] = fv;
+            if (mm) {
+                mm[c] = mm[c] - (mm[c] - fm) * omd;
+                mv[c] = mv[c] - (mv[c] - fv) * omd;
+            }
+        }
+    }
+    __syncthreads();
+    float mu[N], sc[N], bt[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        mu[j] = cst[0][sm.lane * N + j];
+        sc[j] = cst[1][sm.lane * N + j];
+        bt[j] = cst[2][sm.lane * N + j];
+    }
+    grid_zero(zero, zero_vec4);
+    while (r < ML) {
+        const long rn = r + step;
+        Vec16<T> vn[POOL ? 4 : 1];
+        if (rn < ML) {       // next row in flight while this one is computed and stored
+            if (POOL) {
+                const T *src = Y + pr.base(rn) + sm.cg * N;
+                vn[0] = ld16(src);
+                vn[POOL ? 1 : 0] = ld16(src + C);
+                vn[POOL ? 2 : 0] = ld16(src + (long)W * C);
+                vn[POOL ? 3 : 0] = ld16(src + (long)W * C + C);
+            } else vn[0] = ld16(Y + rn * C + sm.cg * N);
+        }
+        Vec16<T> o;
+        if (!POOL) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float z = (v[0].get(j) - mu[j]) * sc[j] + bt[j];
+                o.set(j, fmaxf(z, alpha * z));
+            }
+            st16(A + r * lda + sm.cg * N, o);
+        } else {
+            typename IdxPack<N>::type pack = 0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = (v[POOL ? k : 0].get(j) - mu[j]) * sc[j] + bt[j];
+                    a[k] = (float)(T)fmaxf(z, alpha * z);
+                }
+                const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                const int arg = a[0] == m ? 0 : a[1] == m ? 1 : a[2] == m ? 2 : 3;
+                o.set(j, m);
+                pack |= (typename IdxPack<N>::type)arg << (8 * j);
+            }
+            st16(A + r * lda + sm.cg * N, o);
+            if (idx) *reinterpret_cast<typename IdxPack<N>::type *>(idx + r * C + sm.cg * N) = pack;
+        }
+#pragma unroll
+        for (int k = 0; k < (POOL ? 4 : 1); ++k) v[k] = vn[k];
+        r = rn;
+    }
+}
+
+// backward: dgamma / dbeta from the partial rows (plain sums, as bn_finalize_kernel<1> / reduce_finalize_kernel<1>) + the apply pass
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T *__restrict__ dA, int ldda, const unsigned char *__restrict__ idx, const T *__restrict__ Y,
+                                                               const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ gamma,
+                                                               const float *__restrict__ beta, const float *__restrict__ part, int rows, long plane,
+                                                               float *__restrict__ dgamma, float *__restrict__ dbeta, T *__restrict__ dY, int B, int H, int W, int C,
+                                                               float eps, float alpha, float *__restrict__ zero, long zero_vec4) {
+    constexpr int N = Vec16<T>::N;
+    const SliceMap sm(C, N);
+    __shared__ double sums[2][Y2_SLICE_MAX];
+    __shared__ float cst[2][Y2_SLICE_MAX];
+    const PoolRow pr(H, W, C);
+    const long ML = POOL ? (long)B * pr.OH * pr.OW : (long)B * H * W;
+    const long step = (long)gridDim.x * sm.rpb;
+    long r = (long)blockIdx.x * sm.rpb + sm.row;
+    const long koff[4] = {0, C, (long)W * C, (long)W * C + C};
+    Vec16<T> v[POOL ? 4 : 1], d;
+    typename IdxPack<N>::type pack = 0;
+    auto fetch = [&](long row, Vec16<T> (&yv)[POOL ? 4 : 1], Vec16<T> &dv, typename IdxPack<N>::type &pk) {
+        if (POOL) {
+            const long off = pr.base(row) + sm.cg * N;
+#pragma unroll
+            for (int k = 0; k < (POOL ? 4 : 1); ++k) yv[k] = ld16(Y + off + koff[k]);
+            pk = *reinterpret_cast<const typename IdxPack<N>::type *>(idx + row * C + sm.cg * N);
+        } else yv[0] = ld16(Y + row * C + sm.cg * N);
+        dv = ld16(dA + row * ldda + sm.cg * N);
+    };
+    if (r < ML) fetch(r, v, d, pack);        // in flight under the prologue
+    slice_partial_sums(part, rows, plane, C, sm, sums);
+    if (threadIdx.x < sm.cs) {
+        const float dg = (float)sums[0][threadIdx.x], db = (float)sums[1][threadIdx.x];
+        cst[0][threadIdx.x] = dg;
+        cst[1][threadIdx.x] = db;
+        if (blockIdx.x == 0) {
+            dgamma[sm.c0 + threadIdx.x] = dg;
+            dbeta[sm.c0 + threadIdx.x] = db;
+        }
+    }
+    __syncthreads();
+    const float invM = 1.0f / (float)((long)B * H * W);
+    float mu[N], inv[N], ga[N], bt[N], dgm[N], dbm[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int c = sm.cg * N + j;
+        mu[j] = mean[c];
+        inv[j] = 1.0f / sqrtf(var[c] + eps);
+        ga[j] = gamma[c];
+        bt[j] = beta[c];
+        dgm[j] = cst[0][sm.lane * N + j] * invM;
+        dbm[j] = cst[1][sm.lane * N + j] * invM;
+    }
+    grid_zero(zero, zero_vec4);
+    while (r < ML) {
+        const long rn = r + step;
+        Vec16<T> vn[POOL ? 4 : 1], dn;
+        typename IdxPack<N>::type packn = 0;
+        if (rn < ML) fetch(rn, vn, dn, packn);
+        if (!POOL) {
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float xh = (v[0].get(j) - mu[j]) * inv[j];
+                float z = (v[0].get(j) - mu[j]) * (inv[j] * ga[j]) + bt[j];
+                float g = z >= 0.f ? d.get(j) : alpha * d.get(j);
+                o.set(j, (ga[j] * inv[j]) * (g - dbm[j] - xh * dgm[j]));
+            }
+            st16(dY + r * C + sm.cg * N, o);
+        } else {
+            const long off = pr.base(r) + sm.cg * N;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float da = (int)((pack >> (8 * j)) & 3) == k ? d.get(j) : 0.f;
+                    const float xh = (v[POOL ? k : 0].get(j) - mu[j]) * inv[j];
+                    const float z = (v[POOL ? k : 0].get(j) - mu[j]) * (inv[j] * ga[j]) + bt[j];
+                    const float g = z >= 0.f ? da : alpha * da;
+                    o.set(j, (ga[j] * inv[j]) * (g - dbm[j] - xh * dgm[j]));
+                }
+                st16(dY + off + koff[k], o);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (POOL ? 4 : 1); ++k) v[k] = vn[k];
+        d = dn;
+        pack = packn;
+        r = rn;
     }
 }
 
@@ -1437,10 +1696,26 @@ extern "C" int yolo2_bn_leaky_pool(const void *Y, const float *mean, const float
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
+static int pool_bwd_reduce_impl(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean, const float *var,
+                                const float *gamma, const float *beta, float *dgamma, float *dbeta, double *ws, int *rows, int rows_limit, int B, int H, int W,
+                                int C, float eps, float alpha, int dtype, void *stream);
 extern "C" int yolo2_bn_leaky_pool_bwd_reduce(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean, const float *var,
                                               const float *gamma, const float *beta, float *dgamma, float *dbeta, double *ws, int B, int H, int W,
                                               int C, float eps, float alpha, int dtype, void *stream) {
-    Y2_CHECK_ARG(dP && idx && Y && mean && var && gamma && beta && dgamma && dbeta && ws && lddp >= C);
+    Y2_CHECK_ARG(dgamma && dbeta);
+    return pool_bwd_reduce_impl(dP, lddp, idx, Y, mean, var, gamma, beta, dgamma, dbeta, ws, nullptr, 1024, B, H, W, C, eps, alpha, dtype, stream);
+}
+// reduction alone: partial rows [2][*rows][C] stay in ws (for yolo2_bn_leaky_pool_bwd_apply_fin); at most rows_limit of them
+extern "C" int yolo2_bn_leaky_pool_bwd_reduce_part(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean, const float *var,
+                                                   const float *gamma, const float *beta, double *ws, int *rows, int rows_limit, int B, int H, int W, int C,
+                                                   float eps, float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(rows && rows_limit >= 1);
+    return pool_bwd_reduce_impl(dP, lddp, idx, Y, mean, var, gamma, beta, nullptr, nullptr, ws, rows, rows_limit, B, H, W, C, eps, alpha, dtype, stream);
+}
+static int pool_bwd_reduce_impl(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean, const float *var,
+                                const float *gamma, const float *beta, float *dgamma, float *dbeta, double *ws, int *rows, int rows_limit, int B, int H, int W,
+                                int C, float eps, float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(dP && idx && Y && mean && var && gamma && beta && ws && lddp >= C);
     Y2_CHECK_ARG(pool_args_ok(B, H, W, C, dtype));
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     hipStream_t st = (hipStream_t)stream;
@@ -1455,9 +1730,11 @@ extern "C" int yolo2_bn_leaky_pool_bwd_reduce(const void *dP, int lddp, const un
         nb = (int)(g < big ? g : big);
         if (nb > 1024) nb = 1024;
     }
+    if (nb > rows_limit) nb = rows_limit;
     float *part = (float *)ws;
     Y2_DISPATCH_DTYPE(dtype, bn_pool_bwd_reduce_kernel<T><<<nb, 256, 0, st>>>((const T *)dP, lddp, idx, (const T *)Y, mean, var, gamma, beta, part, B, H, W, C, eps, alpha));
-    reduce_finalize_kernel<1><<<cdiv(C, 16), 256, 0, st>>>(part, nb, C, (long)B * H * W, dgamma, dbeta, C);
+    if (rows) *rows = nb;
+    else reduce_finalize_kernel<1><<<cdiv(C, 16), 256, 0, st>>>(part, nb, C, (long)B * H * W, dgamma, dbeta, C);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -1471,5 +1748,105 @@ extern "C" int yolo2_bn_leaky_pool_bwd_apply(const void *dP, int lddp, const uns
     int grid = rowmap_grid(MP, C, vec, 2);
     Y2_DISPATCH_DTYPE(dtype, bn_pool_bwd_apply_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dP, lddp, idx, (const T *)Y, mean, var, gamma, beta, dgamma, dbeta, (T *)dY, B, H, W, C, eps, alpha));
     Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ---- consumers with the finalisation in their prologue (kernels: bn_leaky_fin_kernel, bn_bwd_apply_fin_kernel)
+static bool fin_shape_ok(int rows, int C, int dtype) {
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    if (rows < 1 || C < vec || C % vec) return false;
+    const int tpr = C / vec;
+    if (tpr & (tpr - 1)) return false;                       // lanes per row must divide 256
+    const int lpr = tpr < 16 ? tpr : 16;
+    return (long)rows * lpr * vec * 8 <= (128L << 10);      // the prologue of EVERY workgroup reads this much: beyond it a separate finalisation is cheaper
+}
+extern "C" int yolo2_bn_fin_supported(int rows, int C, int dtype) { return fin_shape_ok(rows, C, dtype) ? 1 : 0; }
+
+static dim3 slice_grid(long loop_rows, int C, int vec, int rows_per_thread, int part_rows) {
+    const int tpr = C / vec, lpr = tpr < 16 ? tpr : 16, rpb = 256 / lpr, slices = tpr / lpr;
+    long gx = (loop_rows + (long)rpb * rows_per_thread - 1) / ((long)rpb * rows_per_thread);
+    const long per = (long)part_rows * lpr * vec * 8;        // prologue bytes per workgroup
+    long cap = (48L << 20) / (per * slices);                 // <= ~48 MB of L2 reads for all prologues together ...
+    const long floor_ = (512 + slices - 1) / slices;         // ... but never fewer than two workgroups per CU
+    if (cap < floor_) cap = floor_;
+    if (cap > 4096 / slices) cap = 4096 / slices;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    return dim3((unsigned)gx, (unsigned)slices);
+}
+#define Y2_CHECK_ZERO(zero, zero_floats) Y2_CHECK_ARG((zero_floats) >= 0 && (zero_floats) % 4 == 0 && ((zero) || (zero_floats) == 0) && ((uintptr_t)(zero) & 15) == 0)
+
+extern "C" int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var, float *moving_mean,
+                                  float *moving_var, double decay, const float *gamma, const float *beta, void *A, long M, int C, int lda, float eps,
+                                  float alpha, float *zero, long zero_floats, int dtype, void *stream) {
+    Y2_CHECK_ARG(Y && bn_part && shift && mean && var && gamma && beta && A && M > 0 && C > 0 && lda >= C && M < (1L << 31));
+    Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr) && rows <= Y2_BN_PART_ROWS && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ZERO(zero, zero_floats);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(lda % vec == 0);
+    const dim3 grid = slice_grid(M, C, vec, 4, rows);
+    Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, M, mean, var, moving_mean, moving_var,
+                      (float)(1.0 - decay), gamma, beta, (T *)A, nullptr, 1, 1, (int)M, C, lda, eps, alpha, zero, zero_floats / 4));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+extern "C" int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var, float *moving_mean,
+                                       float *moving_var, double decay, const float *gamma, const float *beta, void *P, unsigned char *idx, int B, int H,
+                                       int W, int C, int ldp, float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream) {
+    Y2_CHECK_ARG(Y && bn_part && shift && mean && var && gamma && beta && P && ldp >= C);
+    Y2_CHECK_ARG(pool_args_ok(B, H, W, C, dtype) && ldp % (dtype == YOLO2_BF16 ? 8 : 4) == 0);
+    Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr) && rows <= Y2_BN_PART_ROWS && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ZERO(zero, zero_floats);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    const dim3 grid = slice_grid((long)B * (H / 2) * (W / 2), C, vec, 2, rows);
+    Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin_kernel<T, true><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, (long)B * H * W, mean, var, moving_mean,
+                      moving_var, (float)(1.0 - decay), gamma, beta, (T *)P, idx, B, H, W, C, ldp, eps, alpha, zero, zero_floats / 4));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+extern "C" int yolo2_bn_leaky_bwd_apply_fin(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma, const float *beta,
+                                            const float *part, int rows, long plane_stride, float *dgamma, float *dbeta, void *dY, long M, int C, float eps,
+                                            float alpha, float *zero, long zero_floats, int dtype, void *stream) {
+    Y2_CHECK_ARG(dA && Y && mean && var && gamma && beta && part && dgamma && dbeta && dY && M > 0 && C > 0 && ldda >= C && M < (1L << 31));
+    Y2_CHECK_ARG(plane_stride >= (long)rows * C && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ZERO(zero, zero_floats);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(ldda % vec == 0);
+    const dim3 grid = slice_grid(M, C, vec, 4, rows);
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_apply_fin_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, nullptr, (const T *)Y, mean, var, gamma, beta, part, rows,
+                      plane_stride, dgamma, dbeta, (T *)dY, 1, 1, (int)M, C, eps, alpha, zero, zero_floats / 4));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+extern "C" int yolo2_bn_leaky_pool_bwd_apply_fin(const void *dP, int lddp, const unsigned char *idx, const void *Y, const float *mean, const float *var,
+                                                 const float *gamma, const float *beta, const float *part, int rows, long plane_stride, float *dgamma,
+                                                 float *dbeta, void *dY, int B, int H, int W, int C, float eps, float alpha, float *zero, long zero_floats,
+                                                 int dtype, void *stream) {
+    Y2_CHECK_ARG(dP && idx && Y && mean && var && gamma && beta && part && dgamma && dbeta && dY && lddp >= C);
+    Y2_CHECK_ARG(pool_args_ok(B, H, W, C, dtype) && plane_stride >= (long)rows * C && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ZERO(zero, zero_floats);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    const dim3 grid = slice_grid((long)B * (H / 2) * (W / 2), C, vec, 2, rows);
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_apply_fin_kernel<T, true><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dP, lddp, idx, (const T *)Y, mean, var, gamma, beta, part, rows,
+                      plane_stride, dgamma, dbeta, (T *)dY, B, H, W, C, eps, alpha, zero, zero_floats / 4));
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// the reduction halves of yolo2_bn_leaky_bwd_reduce / yolo2_bn_leaky_pool_bwd_reduce alone: partial rows [2][*rows][C] left in ws for a *_fin consumer
+extern "C" int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
+                                              const float *beta, double *ws, int *rows, int rows_limit, long M, int C, float eps, float alpha, int dtype,
+                                              void *stream) {
+    Y2_CHECK_ARG(dA && Y && mean && var && gamma && beta && ws && rows && rows_limit >= 1 && M > 0 && C > 0 && ldda >= C);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
+    int nb = colsum_grid(M, C, vec);
+    if (nb > rows_limit) nb = rows_limit;
+    Y2_DISPATCH_DTYPE(dtype, bn_bwd_reduce_kernel<T><<<nb, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, (float *)ws, M, C, eps, alpha));
+    Y2_CHECK_LAUNCH();
+    *rows = nb;
     return YOLO2_OK;
 }

@@ -49,6 +49,41 @@ def layer_end_offsets(graph, offsets):
     return ends
 
 
+class _PartPool(object):
+    """Host-side bookkeeping of the partial-row buffers (stream order = call order on the main stream).  A producer takes a CLEAN
+    buffer; its consumer marks it USED and hands one earlier USED buffer to its own kernel to clear (``take_to_zero``)."""
+
+    def __init__(self, n, floats, device):
+        self.bufs = [torch.zeros(floats, dtype=torch.float32, device=device) for _ in range(n)]
+        self.dirty = [0] * n          # floats from the start of the buffer that may be non-zero; 0 = clean
+        self.busy = [False] * n       # produced, not consumed yet
+
+    def acquire(self, floats):
+        """-> index of a clean buffer, now owned by a producer that may dirty ``floats`` floats of it."""
+        for i, (d, b) in enumerate(zip(self.dirty, self.busy)):
+            if d == 0 and not b:
+                break
+        else:       # every buffer is waiting for its consumer or for a clear: clear one that has been consumed (rare; costs a launch)
+            i = next(j for j, b in enumerate(self.busy) if not b)
+            self.bufs[i][:self.dirty[i]].zero_()
+        self.dirty[i] = int(floats)
+        self.busy[i] = True
+        return i
+
+    def consumed(self, i, cleared=False):
+        self.busy[i] = False
+        if cleared:
+            self.dirty[i] = 0
+
+    def take_to_zero(self, exclude):
+        """-> (buffer, floats) of one consumed dirty buffer for the calling consumer's kernel to clear, or (None, 0)."""
+        for i, (d, b) in enumerate(zip(self.dirty, self.busy)):
+            if i != exclude and d and not b:
+                self.dirty[i] = 0
+                return self.bufs[i], d
+        return None, 0
+
+
 class Engine(object):
     def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None):
         if not torch.cuda.is_available():
@@ -159,7 +194,14 @@ class Engine(object):
         self._bind(self.graph)
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
-        self.bn_part = torch.zeros(2 * 256 * max(max_c, 8), dtype=torch.float32, device=dev)   # [2][YOLO2_BN_PART_ROWS][C], kept zero between uses
+        # Partial rows of the fused statistics ([2][YOLO2_BN_PART_ROWS][C] each).  Producers (convolution epilogues) need a zero buffer; the
+        # consumer that finalises the rows in its own prologue only reads them and clears a buffer an EARLIER consumer is done with
+        # (_PartPool below) -- no finalisation launch, no memset launch.  YOLO2_FOLD_FINALIZE=0: separate finalisation kernels (A/B).
+        self.parts = _PartPool(3, 2 * 256 * max(max_c, 8), dev)
+        self.bn_part = self.parts.bufs[0]                       # (kept for callers that drive the two-launch form directly)
+        self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0'
+        self._bz_pending = {}                                    # producer layer -> (buffer, rows): BN-backward sums waiting for their apply pass
+        self._fin_rows_limit = {}
         # scratch sizes come from the library's own queries (include/yolo2_hip.h yolo2_*_workspace_bytes)
         conv_bytes = 0
         for op in self.graph.ops:
@@ -262,18 +304,33 @@ class Engine(object):
         if t is not None:
             t.start(2.0 * self.B * H * W * Nf * real_k, self._phase if k == 3 else '1x1')
         pending = False
+        part = None
         if bn_shift is not None:     # training forward of a batch-normalised layer: statistics from the conv epilogue
-            ops.conv2d_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, bn_shift, self.bn_part)
+            part = self.parts.acquire(2 * 256 * Nf)
+            ops.conv2d_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, bn_shift, self.parts.bufs[part])
         elif bn_bwd is not None:     # data gradient + the producer layer's dgamma / dbeta sums from the same epilogue
             y, mean, var, gamma, beta, dgam, dbet = bn_bwd
+            part = self.parts.acquire(2 * 256 * Nf)
             pending = ops.conv2d_dgrad_bn(P, F, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k, y, mean, var, gamma, beta, dgam, dbet,
-                                          self.bn_part, self.ws, BN_EPS, LEAKY_ALPHA)
+                                          self.parts.bufs[part], self.ws, BN_EPS, LEAKY_ALPHA)
         else:
             ops.conv2d_ws(P, F, bias, O, self.conv_ws, self.B, H, W, Cp, ldp, Nf, ldo, k)
         if t is not None:
             t.stop()
-        if pending:
-            ops.bn_part_to_grads(self.bn_part, Nf, bn_bwd[5], bn_bwd[6])
+        if bn_bwd is not None:
+            if not pending:          # the two-step form ran inside the call: the buffer was not touched
+                self.parts.dirty[part] = 0
+                self.parts.consumed(part)
+                return None
+            rows = ops.last_bn_part_rows()
+            if self.fold_finalize and ops.bn_fin_supported(rows, Nf, self.dtype):
+                return part, rows    # the producer layer's backward apply pass sums the rows itself
+            ops.bn_part_to_grads(self.parts.bufs[part], Nf, bn_bwd[5], bn_bwd[6])      # (reads and clears all rows)
+            self.parts.consumed(part, cleared=True)
+            return None
+        if bn_shift is not None:
+            return part, ops.last_bn_part_rows()
+        return None
 
     def _prepare_filters(self):
         """HWIO f32 masters -> both MFMA operand layouts of every layer, one launch (descriptor table built once)."""
@@ -379,11 +436,17 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     mmean, mvar = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
                     fused = self.training and self.fuse_bn_stats and ldy == op['cout']
-                    self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'],
-                               bn_shift=mmean if fused else None)
+                    produced = self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'],
+                                          bn_shift=mmean if fused else None)
+                    fin = None
                     if fused:
                         # batch moments from the partial sums the convolution left behind (shift = the moving mean)
-                        ops.bn_finalize(self.bn_part, mmean, M, op['cout'], st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                        part, rows = produced
+                        if self.fold_finalize and ops.bn_fin_supported(rows, op['cout'], self.dtype):
+                            fin = (part, rows)              # ... summed by the BN-apply kernel below, in its prologue
+                        else:
+                            ops.bn_finalize(self.parts.bufs[part], mmean, M, op['cout'], st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                            self.parts.consumed(part, cleared=True)
                         mean, var = st['mean'], st['var']
                     elif self.training:
                         ops.bn_stats_ema(yb, st['mean'], st['var'], mmean, mvar, BN_DECAY, self.ws, M, op['cout'])
@@ -391,7 +454,19 @@ class Engine(object):
                     else:
                         mean, var = mmean, mvar
                     pool = self.fused_pool.get(out)
-                    if pool is not None:
+                    if fin is not None:
+                        part, rows = fin
+                        zbuf, zn = self.parts.take_to_zero(part)
+                        if pool is not None:
+                            pb, ldp = self.act[pool['out']]
+                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, st.get('pool_idx'),
+                                                  B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                        else:
+                            ob, ldo = self.act[out]
+                            ops.bn_leaky_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, ob, M, op['cout'], ldo,
+                                             BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                        self.parts.consumed(part)
+                    elif pool is not None:
                         pb, ldp = self.act[pool['out']]
                         ops.bn_leaky_pool(yb, mean, var, gamma, beta, pb, st.get('pool_idx'), B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA)
                     else:
@@ -477,19 +552,44 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     dgam, dbet = self.gvar[op['gamma'].name], self.gvar[op['beta'].name]
                     pool = self.fused_pool.get(out)
+                    # ``pfin`` = (partial rows [2][rows][cout], rows, plane stride): dgamma / dbeta are still unsummed and the apply pass
+                    # below sums them in its prologue (one launch instead of reduce-finalise + apply)
+                    pfin = None
+                    limit = self._fin_limit(cout) if self.fold_finalize else 0
                     if pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
                         dpb, lddp = self.gact[pool['out']]
-                        ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,
-                                                     B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
+                        if limit >= 128:
+                            rows = ops.bn_leaky_pool_bwd_reduce_part(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, self.ws, limit,
+                                                                     B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
+                            pfin = (self.ws, rows, rows * cout)
+                        else:
+                            ops.bn_leaky_pool_bwd_reduce(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws,
+                                                         B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
                     elif op['name'] in reduced:
-                        pass                  # dgamma / dbeta came out of the consumer's data-gradient epilogue
+                        pend = self._bz_pending.pop(op['name'], None)      # sums from the consumer's data-gradient epilogue
+                        if pend is not None:
+                            pfin = (self.parts.bufs[pend[0]], pend[1], 256 * cout, pend[0])
+                    elif limit >= 64:
+                        rows = ops.bn_leaky_bwd_reduce_part(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, self.ws, limit, M, cout, BN_EPS, LEAKY_ALPHA)
+                        pfin = (self.ws, rows, rows * cout)
                     else:
                         ops.bn_leaky_bwd_reduce(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, self.ws, M, cout, BN_EPS, LEAKY_ALPHA)
                     slot = (slot + 1) % 3
                     dy = self.dy_ring[slot]
                     if self.dy_free[slot] is not None:
                         main.wait_event(self.dy_free[slot])       # the filter gradient that last read this buffer is done
-                    if pool is not None:
+                    if pfin is not None:
+                        own = pfin[3] if len(pfin) > 3 else -1
+                        zbuf, zn = self.parts.take_to_zero(own)
+                        if pool is not None:
+                            ops.bn_leaky_pool_bwd_apply_fin(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, pfin[0], pfin[1], pfin[2],
+                                                            dgam, dbet, dy, B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                        else:
+                            ops.bn_leaky_bwd_apply_fin(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, pfin[0], pfin[1], pfin[2], dgam, dbet, dy,
+                                                       M, cout, BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                        if own >= 0:
+                            self.parts.consumed(own)
+                    elif pool is not None:
                         ops.bn_leaky_pool_bwd_apply(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy,
                                                     B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
                     else:
@@ -530,10 +630,12 @@ class Engine(object):
                     dst, ldd, fin = self._grad_sink(x, written)
                     if prod is not None and fin is None:
                         pst = self.conv[prod['name']]
-                        self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout,
-                                   bn_bwd=(self.act[prod['y']][0], pst['mean'], pst['var'], self.var[prod['gamma'].name], self.var[prod['beta'].name],
-                                           self.gvar[prod['gamma'].name], self.gvar[prod['beta'].name]))
+                        pend = self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout,
+                                          bn_bwd=(self.act[prod['y']][0], pst['mean'], pst['var'], self.var[prod['gamma'].name], self.var[prod['beta'].name],
+                                                  self.gvar[prod['gamma'].name], self.gvar[prod['beta'].name]))
                         reduced.add(prod['name'])
+                        if pend is not None:
+                            self._bz_pending[prod['name']] = pend
                     else:
                         self._conv(dy, st['Fdgr'], None, dst, x.h, x.w, ldy, ldy, op['cin'], ldd, k, k * k * cout)
                     if fin:
@@ -571,6 +673,13 @@ class Engine(object):
         self._phase = 'fwd'
         if side is not None:
             main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
+
+    def _fin_limit(self, C):
+        """Most partial rows a reduce_part launch may leave for a *_fin consumer with C channels (0: the shape does not qualify)."""
+        v = self._fin_rows_limit.get(C)
+        if v is None:
+            v = self._fin_rows_limit[C] = ops.bn_fin_rows_limit(C, self.dtype)
+        return v
 
     def _l2(self, op):
         """slim.l2_regularizer on a layer's weights (YOLO v1 fully connected layers): gradient and loss term, on the stream of the

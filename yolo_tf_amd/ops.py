@@ -95,6 +95,68 @@ def bn_leaky_bwd_apply(dA, ldda, Y, mean, var, gamma, beta, dgamma, dbeta, dY, M
          M, C, eps, alpha, dtype_code(Y.dtype), _stream())
 
 
+# ---- consumers that finalise the partial rows in their own prologue (include/yolo2_hip.h: yolo2_bn_leaky_fin & co.)
+def last_bn_part_rows():
+    """Partial rows used by this thread's most recent statistics-producing launch (conv2d_bn / conv2d_dgrad_bn)."""
+    return int(_lib.load().yolo2_last_bn_part_rows())
+
+
+def bn_fin_supported(rows, C, dtype):
+    return bool(_lib.load().yolo2_bn_fin_supported(int(rows), int(C), dtype_code(dtype)))
+
+
+def bn_fin_rows_limit(C, dtype, cap=1024):
+    """Largest power-of-two partial-row count (<= cap) a *_fin consumer accepts for C channels; 0 if the shape never qualifies."""
+    r = cap
+    while r >= 1 and not bn_fin_supported(r, C, dtype):
+        r //= 2
+    return r
+
+
+def _zero_args(zero, zero_floats):
+    return (ptr(zero) if zero_floats else None), int(zero_floats)
+
+
+def bn_leaky_fin(Y, bn_part, rows, shift, mean, var, mm, mv, decay, gamma, beta, A, M, C, lda, eps, alpha, zero=None, zero_floats=0):
+    z, zn = _zero_args(zero, zero_floats)
+    call('yolo2_bn_leaky_fin', ptr(Y), ptr(bn_part), rows, ptr(shift), ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, ptr(gamma), ptr(beta), ptr(A),
+         M, C, lda, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_pool_fin(Y, bn_part, rows, shift, mean, var, mm, mv, decay, gamma, beta, P, idx, B, H, W, C, ldp, eps, alpha, zero=None, zero_floats=0):
+    z, zn = _zero_args(zero, zero_floats)
+    call('yolo2_bn_leaky_pool_fin', ptr(Y), ptr(bn_part), rows, ptr(shift), ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, ptr(gamma), ptr(beta),
+         ptr(P), ptr(idx), B, H, W, C, ldp, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_bwd_apply_fin(dA, ldda, Y, mean, var, gamma, beta, part, rows, plane_stride, dgamma, dbeta, dY, M, C, eps, alpha, zero=None, zero_floats=0):
+    z, zn = _zero_args(zero, zero_floats)
+    call('yolo2_bn_leaky_bwd_apply_fin', ptr(dA), ldda, ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(part), rows, plane_stride,
+         ptr(dgamma), ptr(dbeta), ptr(dY), M, C, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_pool_bwd_apply_fin(dP, lddp, idx, Y, mean, var, gamma, beta, part, rows, plane_stride, dgamma, dbeta, dY, B, H, W, C, eps, alpha,
+                                zero=None, zero_floats=0):
+    z, zn = _zero_args(zero, zero_floats)
+    call('yolo2_bn_leaky_pool_bwd_apply_fin', ptr(dP), lddp, ptr(idx), ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(part), rows, plane_stride,
+         ptr(dgamma), ptr(dbeta), ptr(dY), B, H, W, C, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+
+
+def bn_leaky_bwd_reduce_part(dA, ldda, Y, mean, var, gamma, beta, ws, rows_limit, M, C, eps, alpha):
+    """-> number of partial rows left in ``ws`` ([2][rows][C] f32)."""
+    rows = ctypes.c_int(0)
+    call('yolo2_bn_leaky_bwd_reduce_part', ptr(dA), ldda, ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(ws), ctypes.byref(rows), rows_limit, M, C,
+         eps, alpha, dtype_code(Y.dtype), _stream())
+    return rows.value
+
+
+def bn_leaky_pool_bwd_reduce_part(dP, lddp, idx, Y, mean, var, gamma, beta, ws, rows_limit, B, H, W, C, eps, alpha):
+    rows = ctypes.c_int(0)
+    call('yolo2_bn_leaky_pool_bwd_reduce_part', ptr(dP), lddp, ptr(idx), ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(ws), ctypes.byref(rows),
+         rows_limit, B, H, W, C, eps, alpha, dtype_code(Y.dtype), _stream())
+    return rows.value
+
+
 def bn_leaky_pool(Y, mean, var, gamma, beta, P, idx, B, H, W, C, ldp, eps, alpha):
     call('yolo2_bn_leaky_pool', ptr(Y), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(P), ptr(idx), B, H, W, C, ldp, eps, alpha,
          dtype_code(Y.dtype), _stream())
