@@ -42,8 +42,13 @@ F32_MATRIX_PEAK_TFLOPS = 157.3
 # 1.00 on bn_leaky_kernel (profiles/r01_hbm_traffic_pmc_final.md: 99.1 MB fetched + 27.2 MB written per launch).  The counters
 # sit between L2 and the fabric: Infinity-Cache hits are included (the 3072-channel layer alone re-reads its filter slab from
 # the MALL 11 times: 0.8 GB).  Algorithmic bytes (every operand once): 31.9 MB, 40.4 GFLOP per launch.
-IGEMM_HBM_BYTES_PER_LAUNCH = 124.2e6      # profiles/r02_bench_roofline_check.txt: FETCH_SIZE x 1024 x 2 (95.0 MB) + WRITE_SIZE x 1024 (29.2 MB), 24 launches
-IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = 31.9e6
+# The two figures live in a tracked profile file together with the commit they were measured at (they go stale with every kernel change;
+# a constant pasted here would hide that): profiles/dominant_kernel_pmc.json, written from scripts/gpu_traffic.sh runs.
+PMC_PROFILE = os.path.join(ROOT, 'profiles', 'dominant_kernel_pmc.json')
+with open(PMC_PROFILE) as _f:
+    PMC = json.load(_f)
+IGEMM_HBM_BYTES_PER_LAUNCH = float(PMC['traffic_bytes_per_launch'])
+IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH = float(PMC['algorithmic_bytes_per_launch'])
 TRAIN_GFLOP_PER_IMG = {20: 104.396, 80: 104.707}    # 2*(3*sum(MACs) - MACs(conv0))
 
 
@@ -74,7 +79,7 @@ class KernelTimer(object):
         self.tags.append(self._cur[2])
         self._cur = None
 
-    NOOP_KERNEL_MS = 0.0034      # median duration rocprofv3 reports for the empty kernel itself (64 launches: 0.6 .. 6.9 us; profiles/r02_bench_roofline_check.txt)
+    NOOP_KERNEL_MS = float(PMC['empty_kernel_duration_ms'])      # median duration rocprofv3 reports for the empty kernel itself (64 launches: 0.6 .. 6.9 us)
 
     def calibrate(self, n=64):
         """What a bracket adds to the kernel inside it.  A HIP-event pair measures from the completion of the start event to the
@@ -340,6 +345,7 @@ def main():
                                                          'brackets around an empty kernel (its own 3.4 us excluded); frac from the raw brackets: %.4f'
                                                          % (ks['tflops'] * ks['total_ms'] / (ks['raw_bracket_avg_ms'] * ks['launches']) / peak)},
                                'algorithmic_bytes_per_launch': IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH, 'traffic_unit': 'bytes per launch (PMC, separate passes)',
+                               'traffic_source': {'file': 'profiles/dominant_kernel_pmc.json', 'measured_at_commit': PMC['measured_at_commit']},
                                'measured_over': '%d instrumented single-stream training steps run right after the timed region '
                                                 '(events inside it cost 11 %% of the step)' % min(args.steps, 10),
                                'forward_launches_tflops': kf['tflops'] if kf else None, 'data_gradient_launches_tflops': kd['tflops'] if kd else None,

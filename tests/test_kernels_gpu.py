@@ -189,6 +189,17 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
     np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
 
 
+def _bn_bwd_sums_oracle(dA, yprev, mean, var, gamma, beta, eps, alpha=0.1):
+    """dgamma, dbeta of a = leaky(bn(yprev)) for the activation gradient dA, by the ORACLE's formulas (R.bn_apply, R.leaky_relu_grad,
+    R.bn_train_bwd); inputs [M, C] float arrays."""
+    M, C = dA.shape
+    y4 = yprev.reshape(1, 1, M, C).astype(np.float32)
+    z = R.bn_apply(y4, mean, var, gamma, beta, eps)
+    dz = R.leaky_relu_grad(z, dA.reshape(1, 1, M, C).astype(np.float32), alpha)
+    _, dg, db = R.bn_train_bwd(y4, mean, var, gamma, dz, eps)
+    return dg.astype(np.float64), db.astype(np.float64)
+
+
 TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 256), (8, 13, 13, 1024, 504), (16, 26, 26, 256, 136),
               (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256)]
 
@@ -273,6 +284,12 @@ def test_conv_tap_fused_3x3(ops, shape, epilogue):
         for a, b, name in ((out[1][2][0], out[0][2][0], 'dgamma'), (out[1][2][1], out[0][2][1], 'dbeta')):
             assert np.abs(host(a) - host(b)).max() <= 2e-2 * np.abs(host(b)).max(), name
         assert float(out[1][2][2].abs().max()) == 0.0
+        # ... and DIRECTLY against the oracle's BN + leaky backward sums, evaluated on the gradient tile the kernel stored (y1) --
+        # the fused epilogue is not only "equal to the unfused GPU pair"
+        _, _, _, _, yprev, pm, pv, pg, pb = out[1][2]
+        dg_o, db_o = _bn_bwd_sums_oracle(y1[:, :Cout], host(yprev).reshape(M, Cout), host(pm), host(pv), host(pg), host(pb), 1e-3)
+        for got, ref, name in ((out[1][2][0], dg_o, 'dgamma'), (out[1][2][1], db_o, 'dbeta')):
+            assert np.abs(host(got) - ref).max() <= 3e-3 * np.abs(ref).max(), (name, np.abs(host(got) - ref).max(), np.abs(ref).max())
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
@@ -325,6 +342,16 @@ def test_conv_dgrad_bn_fused_sums(ops, shape, fused, mode):
     for got, ref, name in ((dg, dg_ref, 'dgamma'), (db, db_ref, 'dbeta')):
         g, r = host(got).astype(np.float64), host(ref).astype(np.float64)
         assert np.abs(g - r).max() <= tol * np.abs(r).max(), (name, shape, mode, np.abs(g - r).max(), np.abs(r).max())
+    # the same three results DIRECTLY against the oracle (the comparison above is GPU vs GPU): dX vs the oracle's data gradient on the
+    # same (rounded) operands, dgamma / dbeta vs the oracle's BN + leaky backward sums of the dX the kernel stored
+    rnd = (lambda a: a) if mode == 'f32' else bf16_round
+    dy_np = host(dy).reshape(B, H, W, ldy)[..., :Cout]
+    dx_o = R.conv2d_dgrad(dy_np, rnd(w)).reshape(M, Cin)
+    dx_g = host(dx).reshape(M, ldx)[:, :Cin]
+    assert_close(dx_g, dx_o, F32_RTOL if mode == 'f32' else BF16_RTOL, 'dgrad_bn dX vs oracle %s %s' % (shape, mode))
+    dg_o, db_o = _bn_bwd_sums_oracle(dx_g, host(yprev).reshape(M, Cin), host(mean), host(var), host(gamma), host(beta), 1e-3)
+    for got, ref, name in ((dg, dg_o, 'dgamma'), (db, db_o, 'dbeta')):
+        assert np.abs(host(got) - ref).max() <= (3e-4 if mode == 'f32' else 3e-3) * np.abs(ref).max(), (name, shape, mode)
 
 
 WGRAD_SHAPES = CONV_SHAPES + [(2, 13, 13, 256, 128, 3), (2, 26, 26, 128, 256, 1), (4, 52, 52, 32, 64, 3)]

@@ -438,6 +438,42 @@ def read_t(e, t, grad=False):
     return v.float().cpu().numpy().reshape(e.B, t.h, t.w, t.c)
 
 
+def forward_teacher_forced(e, scope, params0, f32):
+    """Forward, layer by layer, on the GPU's OWN stored inputs: raw convolution output vs the oracle's convolution of the stored input,
+    BN + leaky (+ fused 2x2 pool) output vs the oracle's formulas on the stored y and batch moments, stand-alone pools and reorg
+    bit-exact.  A forward bug that is self-consistent (and would pass a backward comparison that starts from the GPU's forward state)
+    fails here.  Returns [(rel-L2, what)] sorted worst first."""
+    q = (lambda a: a) if f32 else R.bf16_round
+    tol_fwd, tol_fwd_l2 = (2e-5, 1e-5) if f32 else (8e-3, 2e-3)     # bf16: one output ulp where the f32 sums round differently
+    fwd_report = []
+    for op in e.graph.ops:
+        if op['kind'] == 'conv':
+            name = op['name'][len(scope) + 1:]
+            xin = read_t(e, op['x'])
+            conv = R.conv2d(xin, q(params0[name + '/weights']))
+            if op['bn']:
+                y = read_t(e, op['y'])
+                fwd_report.append((rel_l2(y, q(conv)), name + ' y'))
+                assert rel(y, q(conv)) <= tol_fwd and fwd_report[-1][0] <= tol_fwd_l2, '%s conv output: max %.3e l2 %.3e' % (name, rel(y, q(conv)), fwd_report[-1][0])
+                st = e.conv[op['name']]
+                bname = name + ('/BatchNorm/beta' if (name + '/BatchNorm/beta') in params0 else '/biases')
+                a = q(R.leaky_relu(R.bn_apply(y, st['mean'].cpu().numpy(), st['var'].cpu().numpy(), params0[name + '/BatchNorm/gamma'], params0[bname])))
+                pool = e.fused_pool.get(op['out'])
+                got_a, ref_a = (read_t(e, pool['out']), R.max_pool(a, 2)) if pool is not None else (read_t(e, op['out']), a)
+                fwd_report.append((rel_l2(got_a, ref_a), name + ' activation'))
+                assert rel(got_a, ref_a) <= tol_fwd and fwd_report[-1][0] <= tol_fwd_l2, '%s activation: max %.3e' % (name, rel(got_a, ref_a))
+            else:
+                ref_o = q(conv + params0[name + '/biases'])
+                assert rel(read_t(e, op['out']), ref_o) <= tol_fwd, name
+        elif op['kind'] == 'pool' and op['x'] not in e.fused_pool:
+            assert np.array_equal(read_t(e, op['out']), R.max_pool(read_t(e, op['x']), op['stride'])), op['name']
+        elif op['kind'] == 'reorg':
+            assert np.array_equal(read_t(e, op['out']), R.reorg(read_t(e, op['x']))), op['name']
+    fwd_report.sort(reverse=True)
+    return fwd_report
+
+
+
 @pytest.mark.parametrize('inference,size,dtype,B,classes', [
     ('darknet', 160, 'f32', 2, 20), ('tiny', 160, 'f32', 2, 20), ('darknet', 160, 'f32', 2, 80),
     ('darknet', 416, 'bf16', 16, 20),       # BASELINE configs[1]: the benchmarked shape and dtype
@@ -482,6 +518,9 @@ def test_backward_layerwise_teacher_forced(basedir, inference, size, dtype, B, c
     dnet_ref = q(R.loss_backward(m, labels, aux, HP, classes))
     dnet = read_t(e, out_t, grad=True)
     assert rel(dnet, dnet_ref) <= (1e-4 if f32 else 8e-3), 'dlogits rel err %.3e' % rel(dnet, dnet_ref)
+
+    fwd_report = forward_teacher_forced(e, scope, params0, f32)
+    print('\n%s %d %s B%d C%d teacher-forced forward, worst rel-L2: %s' % (inference, size, dtype, B, classes, ['%s %.1e' % (n, r) for r, n in fwd_report[:4]]))
 
     # ---- every convolution layer, in graph order
     inputs = set(e.graph.inputs.values())
@@ -630,6 +669,49 @@ def test_multi_scale_bf16_training_steps(basedir):
         assert np.isfinite(loss) and 0 < loss < 10, (size, loss)
     assert sess.global_step == 2 * len(sizes)
     assert torch.isfinite(sess.engine.params).all() and float((sess.engine.params - before).abs().max()) > 0
+
+
+def test_multi_scale_every_size_of_configs3(basedir):
+    """All ten input sizes of BASELINE configs[3] ({320, 352, ..., 608}: kernel variants are chosen per shape, so every size takes its
+    own plans), not only the five the oracle tests touch.  At 384 / 448 / 480 / 512 / 576 every layer of the bf16 forward is checked against
+    the oracle on the engine's own stored inputs (forward_teacher_forced).  Per size, on shared weights: the bf16 engine's logits agree with the f32
+    engine's (whose arithmetic is oracle-checked at 320 / 352 / 608) within the whole-network bf16 band, the training loss is finite and equal between the
+    two dtypes within 3 %, padding lanes stay zero, gradients are finite, and a launch plan was recorded for the last convolution."""
+    from yolo_tf_amd import ops
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B, classes = 2, 20
+    sizes = list(range(320, 609, 32))
+    b, _ = make_builder('darknet', classes, 608, True, basedir)
+    sess = {dt: TrainSession(b, B, dtype=dt, optimizer='adam', learning_rate=1e-4, seed=5, sizes=[(s_, s_) for s_ in sizes]) for dt in ('f32', 'bf16')}
+    g = torch.Generator(device='cuda').manual_seed(7)
+    for size in sizes:
+        cells = size // 32
+        images = torch.rand(B, size, size, 3, device='cuda', generator=g) * 255
+        labels = data.synthetic_batch(B, classes, cells, cells, seed=size)
+        res = {}
+        for dt, se in sess.items():
+            se.set_size(size, size)
+            se.upload_labels(labels)
+            se.forward_backward(images)
+            plan = ops.last_conv_plan()
+            loss = se.fetch()['total_loss']
+            e = se.engine
+            out = e.output()
+            assert (out.h, out.w) == (cells, cells)
+            logits = read_t(e, out)
+            pad = e.act[out][0].float().reshape(-1, 128)[:B * cells * cells, 125:]
+            assert torch.all(pad == 0), (size, dt)
+            assert np.isfinite(loss) and 0 < loss < 10, (size, dt, loss)
+            assert torch.isfinite(e.grads).all(), (size, dt)
+            assert plan['BM'] in (-1, 128, 256) and plan['grid_x'] != 0, (size, dt, plan)
+            res[dt] = (loss, logits)
+            if dt == 'bf16' and size in (384, 448, 480, 512, 576):      # the sizes no oracle test touches: every layer's forward vs the oracle
+                worst = forward_teacher_forced(e, 'yolo2_darknet', strip(e.get_variables(), 'yolo2_darknet'), False)
+                print('\n%d bf16 teacher-forced forward, worst rel-L2: %s' % (size, ['%s %.1e' % (n, r) for r, n in worst[:3]]))
+        # (22 layers of bf16 storage on 100-361 samples per channel: the same band as the bf16-vs-oracle network tests; a wrong tile or tap is O(1))
+        assert rel_l2(res['bf16'][1], res['f32'][1]) <= 0.25 and rel(res['bf16'][1], res['f32'][1]) <= 0.5, (size, rel_l2(res['bf16'][1], res['f32'][1]), rel(res['bf16'][1], res['f32'][1]))
+        assert abs(res['bf16'][0] - res['f32'][0]) <= 3e-2 * abs(res['f32'][0]), (size, res['bf16'][0], res['f32'][0])
 
 
 def test_tensorflow_checkpoint_and_event_file_round_trip(basedir, tmp_path):

@@ -2,7 +2,7 @@
 (train.py:141-145 summary_writer, config.ini:63 scalars) and V2 checkpoints (tf.train.Saver via slim, train.py:130-145,
 detect.py:104-106).  Proto encodings are checked against google.protobuf's serializer on the published schemas (an independent
 implementation of the wire format); the LevelDB table layout against a second, minimal parser written here from the format
-description; checksums against corruption.  No TF-written file exists in this image: see yolo_tf_amd/tf_checkpoint.py's header."""
+description; checksums against corruption.  No TF-written file exists in this image: see yolo_tf_amd/C.py's header."""
 import os
 import struct
 import sys
@@ -194,3 +194,67 @@ def test_latest_checkpoint_follows_the_state_file(tmp_path):
     assert C.latest_checkpoint(d).endswith('model.ckpt-100')
     open(os.path.join(d, 'checkpoint'), 'w').write('model_checkpoint_path: "model.ckpt-20"\nall_model_checkpoint_paths: "model.ckpt-20"\n')
     assert C.latest_checkpoint(d).endswith('model.ckpt-20')
+
+
+class _FakeEngine(object):
+    """Just enough of engine.Engine for C.save / restore: variables by name, the flat parameter layout, set_variables."""
+
+    def __init__(self):
+        from yolo_tf_amd import graph as G
+        self.graph = G.Graph()
+        x = G.placeholder(self.graph, 'image', 32, 32)
+        G.conv2d(x, 8, 3, scope='net/conv0')
+        self.values = {v.name: np.full(v.shape, i + 1, np.float32) for i, v in enumerate(self.graph.variables.values())}
+        self.param_offsets, off = {}, 0
+        for v in self.graph.trainable():
+            self.param_offsets[v.name] = (off, v.size)
+            off += v.size
+        self.n = off
+
+    def get_variables(self):
+        return dict(self.values)
+
+    def set_variables(self, values, strict=True):
+        self.values.update({k: np.asarray(v, np.float32) for k, v in values.items()})
+
+
+class _FakeSession(object):
+    def __init__(self):
+        import torch
+        import types
+        self.engine = _FakeEngine()
+        self.global_step = 0
+        self.optimizer = types.SimpleNamespace(name='adam', slots=[torch.zeros(self.engine.n), torch.ones(self.engine.n)])
+
+
+def test_saver_keeps_five_checkpoints_and_lists_them(tmp_path):
+    """[TF-sem] tf.train.Saver(max_to_keep=5): old .index / .data files are pruned, the state file lists the kept ones."""
+    s = _FakeSession()
+    for step in (10, 20, 30, 40, 50, 60, 70):
+        s.global_step = step
+        C.save(str(tmp_path), s)
+    kept = sorted(int(f.split('-')[1].split('.')[0]) for f in os.listdir(str(tmp_path)) if f.endswith('.index'))
+    assert kept == [30, 40, 50, 60, 70]
+    assert not [f for f in os.listdir(str(tmp_path)) if f.startswith('model.ckpt-10.') or f.startswith('model.ckpt-20.')]
+    state = open(os.path.join(str(tmp_path), 'checkpoint')).read()
+    assert state.startswith('model_checkpoint_path: "model.ckpt-70"')
+    assert [int(l.split('-')[1].rstrip('"')) for l in state.splitlines() if l.startswith('all_model')] == kept
+    assert C.checkpoint_step(C.latest_checkpoint(str(tmp_path))) == 70
+
+
+def test_transfer_from_a_tf_checkpoint_takes_global_step_unless_excluded(tmp_path):
+    """The reference's -t / -e transfer restores slim.get_variables_to_restore(exclude=...), which includes global_step: the learning
+    rate schedule continues from the donor's step (both containers behave the same; train.py passes the session to both)."""
+    donor = _FakeSession()
+    donor.global_step = 1234
+    prefix = C.save(str(tmp_path), donor)
+    s = _FakeSession()
+    s.optimizer.slots[0].fill_(7)
+    assert C.restore(prefix, s, variables_only=True) == 1234
+    assert s.global_step == 1234 and float(s.optimizer.slots[0][0]) == 7      # slots untouched by a transfer
+    s2 = _FakeSession()
+    C.restore(prefix, s2, exclude=['global_step'], variables_only=True)
+    assert s2.global_step == 0
+    s3 = _FakeSession()
+    C.restore(prefix, s3)                                             # full resume: step and Adam slots
+    assert s3.global_step == 1234 and float(s3.optimizer.slots[1][0]) == 1

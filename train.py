@@ -18,6 +18,7 @@ import argparse
 import configparser
 import logging
 import os
+import re
 import shutil
 import time
 
@@ -50,7 +51,8 @@ def make_args():
     parser.add_argument('--level', help='logging level')
     parser.add_argument('--master', default='', help='accepted for compatibility (rendezvous comes from torch.distributed.run)')
     parser.add_argument('--task', type=int, default=0, help='accepted for compatibility (rank comes from RANK)')
-    parser.add_argument('--data', default='synthetic', help="'synthetic', 'cache' (the reference's TFRecord cache of -p profiles) or a .npz file")
+    parser.add_argument('--data', default='cache', help="'cache' (default, as the reference's train.py:98-100: the TFRecord cache of the -p profiles under cachedir), "
+                        "'synthetic' (random images and labels: benchmarking / smoke runs) or a .npz file")
     parser.add_argument('--dtype', default=None, choices=['bf16', 'f32'], help='overrides [mi355x] dtype')
     parser.add_argument('--ckpt_format', default='npz', choices=['npz', 'tf'], help="checkpoint container: 'npz' (every optimizer) or 'tf' (TensorFlow V2 bundle, as the reference's tf.train.Saver writes)")
     return parser.parse_args()
@@ -132,21 +134,33 @@ def main():
     logging.warning('optimizer=%s, dtype=%s, world=%d, parameters=%d' % (args.optimizer, dtype, world, session.engine.n_params))
     # rank 0 alone chooses and reads the checkpoint; the others receive parameters, statistics, optimizer slots and
     # global_step from it (same seed -> same initial weights anyway, but a restore must not depend on what each rank sees)
-    latest = checkpoint.latest_checkpoint(logdir) if rank == 0 else None
-    latest_tf = tf_checkpoint.latest_checkpoint(logdir) if rank == 0 and not latest else None     # a logdir written by the reference (or --ckpt_format tf)
-    if latest:
-        step = checkpoint.restore(latest, session)
-        logging.warning('resuming from %s (global_step=%d)' % (latest, step))
-    elif latest_tf:
-        step = tf_checkpoint.restore(latest_tf, session)
-        logging.warning('resuming from TensorFlow checkpoint %s (global_step=%d)' % (latest_tf, step))
-    elif args.transfer and rank == 0:
-        path = os.path.expanduser(os.path.expandvars(args.transfer))
-        logging.warning('transferring from ' + path)
-        if os.path.exists(path + '.index'):                     # a TensorFlow checkpoint prefix, like the reference's -t argument
-            tf_checkpoint.restore(path, engine=session.engine, exclude=args.exclude)
-        else:
-            checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+    # Both containers may sit in one logdir (a run resumed with the other --ckpt_format, or a logdir the reference wrote): the one
+    # with the HIGHER global step wins, so a restart never falls back to an older state.  A failure on rank 0 (corrupt file, shape
+    # mismatch) is agreed on before anyone enters the broadcast of sync_replicas -- the other ranks would wait there forever.
+    error = None
+    if rank == 0:
+        try:
+            latest = checkpoint.latest_checkpoint(logdir)
+            latest_tf = tf_checkpoint.latest_checkpoint(logdir)            # a logdir written by the reference (or --ckpt_format tf)
+            step_npz = int(re.search(r'model\.ckpt-(\d+)\.npz$', latest).group(1)) if latest else -1
+            if latest and step_npz >= tf_checkpoint.checkpoint_step(latest_tf):
+                step = checkpoint.restore(latest, session)
+                logging.warning('resuming from %s (global_step=%d)' % (latest, step))
+            elif latest_tf:
+                step = tf_checkpoint.restore(latest_tf, session)
+                logging.warning('resuming from TensorFlow checkpoint %s (global_step=%d)' % (latest_tf, step))
+            elif args.transfer:
+                path = os.path.expanduser(os.path.expandvars(args.transfer))
+                logging.warning('transferring from ' + path)
+                if os.path.exists(path + '.index'):                     # a TensorFlow checkpoint prefix, like the reference's -t argument
+                    tf_checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+                else:
+                    checkpoint.restore(path, session, exclude=args.exclude, variables_only=True)
+        except Exception as e:       # noqa: BLE001  (re-raised below, on every rank)
+            error = e
+    (failed,) = agree([error is not None], session.engine.device)
+    if failed:
+        raise error if error is not None else RuntimeError('rank 0 could not restore the checkpoint (see its log)')
     sync_replicas(session)
     logging.warning('global_step=%d, learning_rate=%g' % (session.global_step, session.lr_fn(session.global_step)))
     if args.data == 'synthetic':
@@ -186,8 +200,15 @@ def main():
         want_summary, want_save = agree([want_summary, want_save], device)
         if want_summary:
             s = session.fetch()
+            shard_error = None
             if hasattr(data, 'pipe'):
-                data.pipe.check()        # objects outside the grid / bad class ids / negative extents: the reference raises there
+                try:
+                    data.pipe.check()    # objects outside the grid / bad class ids / negative extents: the reference raises there
+                except Exception as e:   # noqa: BLE001  (a shard-local error: agreed on, then raised by every rank)
+                    shard_error = e
+            (bad_shard,) = agree([shard_error is not None], device)
+            if bad_shard:
+                raise shard_error if shard_error is not None else RuntimeError('another rank found invalid objects in its data shard')
             rate = n_rate * args.batch_size * world / (time.time() - t_rate)
             if rank == 0:
                 writer.add_training_summary(session.global_step, s)

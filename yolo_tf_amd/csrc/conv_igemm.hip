@@ -66,19 +66,8 @@ template <> struct Mma<float> {
     }
 };
 
-// Timing-ablation builds only (scripts/abl_build.sh -> a separate .so, never the product): bit 0 no epilogue, 1 no statistics
-// atomics, 2 no MFMA, 3 no fragment reads (and no MFMA), 4 no operand DMA.  0 in every shipped build.
-#ifndef Y2_ABL
-#define Y2_ABL 0
-#endif
-#if Y2_ABL          // (bf16 only: hipcc 7.2 drops the host stub of one f32 instantiation in some ablated bodies)
-#undef Y2_DISPATCH_DTYPE
-#define Y2_DISPATCH_DTYPE(dtype, ...)                                   \
-    do {                                                                \
-        if ((dtype) == YOLO2_BF16) { typedef bf16 T; __VA_ARGS__; }     \
-        else { yolo2_set_error("ablation build: bf16 only"); return YOLO2_E_ARG; } \
-    } while (0)
-#endif
+// (Timing-ablation hooks -- no epilogue / no MFMA / no fragment reads / no DMA builds -- live in scripts/experiments/conv_igemm_ablation_hooks.patch,
+// applied to a COPY of this file by scripts/abl_build.sh; the product source carries none.)
 #define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
@@ -246,21 +235,13 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             bool ok = (a_mask[i] & tapbit) != 0;
             if (CTAIL) ok = ok && (c0b + a_cb[i] < cp_bytes);
             const unsigned voff = ok ? a_voff[i] + offA : Y2_OOB;
-#if !(Y2_ABL & 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)(As + (wave * A_IT + i) * 1024), 16, voff, 0, 0, 0);
-#else
-            asm volatile("" ::"v"(voff));
-#endif
         }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) {
             unsigned voff = b_voff[i] + offB;           // an OOB row stays out of range: OOB + offB < 2^32 and >= 2^31
             if (CTAIL) voff = (c0b + b_cb[i] < cp_bytes) ? voff : Y2_OOB;
-#if !(Y2_ABL & 16)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)(Bs + (wave * B_IT + i) * 1024), 16, voff, 0, 0, 0);
-#else
-            asm volatile("" ::"v"(voff));
-#endif
         }
         ++kt_issue;
         i_stage = (i_stage + 1 == NSTAGE) ? 0 : i_stage + 1;
@@ -293,7 +274,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
         // 128-byte rows, 8 waves of 32 x 64 (bf16): all twelve fragment reads of the K step are issued before its first MFMA (48 VGPRs)
         // and the MFMAs wait with a falling lgkmcnt; left to itself hipcc issues read, wait, MFMA, read, wait, MFMA ... and every
         // MFMA pair pays a full LDS latency (the tap-fused kernel below gained 15 % from the same change).
-        constexpr bool HOIST = sizeof(T) == 2 && CH == 8 && NW == 8 && BM == 128 && Y2_ABL == 0;
+        constexpr bool HOIST = sizeof(T) == 2 && CH == 8 && NW == 8 && BM == 128;
         if constexpr (HOIST) {
             constexpr int KK = BK / Mma<T>::KSTEP;
             typename Mma<T>::Frag af[KK][TM], bf[KK][TN];
@@ -327,29 +308,17 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-#if Y2_ABL & 8
-                asm volatile("" : "=v"(af[i]));
-#else
                 af[i] = *reinterpret_cast<const typename Mma<T>::Frag *>(As + i * 32 * ROWB + boff);
-#endif
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-#if Y2_ABL & 8
-                asm volatile("" : "=v"(bf[j]));
-#else
                 bf[j] = *reinterpret_cast<const typename Mma<T>::Frag *>(Bs + j * 32 * ROWB + boff);
-#endif
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-#if Y2_ABL & 12
-                    asm volatile("" ::"v"(af[i]), "v"(bf[j]));
-#else
                     acc[i][j] = Mma<T>::mma(af[i], bf[j], acc[i][j]);
-#endif
                 }
         }
     }
@@ -472,9 +441,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     // 4.6k MFMA cycles; its 32 narrow store instructions per wave took longer than that).  Instead each wave rounds its
     // sub-tile into a private, padded LDS image (the DMA ring is idle by now), computes the statistics from the rounded values
     // on the way, and reads it back row-major: 16 bytes (8 bf16 / 4 f32 consecutive filters of one pixel) per lane per store.
-#if Y2_ABL & 1      // a run-time-false guard keeps the accumulators live (an inline-asm use of a 16-float vector makes hipcc 7.2 drop the host stub)
-    if (act_alpha == 7777.0f)
-#endif
     {
     constexpr int WROWS = TM * 32, WROWB = TN * 32 * (int)sizeof(T), WSTRIDE = WROWB + 16, WCPR = WROWB / 16;
     constexpr bool WIDE_FITS = SPLITK != 1 && NW * WROWS * WSTRIDE <= NSTAGE * STAGE;
@@ -541,7 +507,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             if (stats) {
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32 && n_ok && !(Y2_ABL & 2)) {
+                if (lane < 32 && n_ok) {
                     const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                     float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
                     if (stats_unique) { *p1 = s1; *p2 = s2; }      // one writer per (row, filter): a store into the zeroed row
@@ -620,11 +586,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
 // Every wave issues exactly Y2T_LOADS DMA instructions per K step, so "filter tile kt has landed" is vmcnt(Y2T_LOADS) at every
 // step; halo pieces are older than the filter tile of their first use by construction (issued in slots 0..5 of the previous
 // chunk, the filter tile of (c+1, tap 0) in slot 7).
-// timing-ablation builds only (scripts/abl_build.sh with -DY2_TABL=bits): 1 no MFMA, 2 no fragment reads (and no MFMA), 4 no DMA inside
-// the K loop, 8 no barrier inside the K loop.  0 in every shipped build.
-#ifndef Y2_TABL
-#define Y2_TABL 0
-#endif
 #define Y2T_BM 256
 #define Y2T_BN 128
 #define Y2T_BBYTES (Y2T_BN * 128)
@@ -816,26 +777,18 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
     auto step = [&](int kt, bf16x8 (&fa)[4][TM], bf16x8 (&fb)[4][TN], bf16x8 (&na)[4][TM], bf16x8 (&nb)[4][TN]) {
         auto mfma_one = [&](int kk, int w) {             // w: 0..3 = (i, j) of the accumulator tile
             const int i = w >> 1, j = w & 1;
-#if (Y2_TABL & 1) && defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" ::"v"(fa[kk][i]), "v"(fb[kk][j]));
-#else
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-#endif
         };
         auto read_one = [&](int idx) {                   // idx 0..15: 16-k group idx / 4; order A0, B0, A1, B1
-#if !(Y2_TABL & 2)
             const int kk = idx >> 2, w = idx & 3;
             if (w == 0 || w == 2) na[kk][w >> 1] = *(lds_frag_ptr)(uintptr_t)(ad_next.abase[w >> 1] + (ad_next.ax[w >> 1] ^ (unsigned)(kk * 32)));
             else nb[kk][w >> 1] = *(lds_frag_ptr)(uintptr_t)(ad_next.bbase + (bx ^ (unsigned)(kk * 32)) + (unsigned)((w >> 1) * 32 * ROWB));
-#endif
         };
 #pragma unroll
         for (int w = 0; w < 4; ++w) mfma_one(0, w);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 3) * Y2T_LOADS) : "memory");      // all but the newest NSB-3 slots: steps kt and kt+1 are in LDS
-#if !(Y2_TABL & 8)
         __builtin_amdgcn_s_barrier();                    // ... for every wave; nobody reads step kt-1's operands any more
-#endif
         __builtin_amdgcn_sched_barrier(0);
         FragAddr ad_new;
         next_step(n_chunk, n_tap);
@@ -846,9 +799,7 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
             mfma_one(1 + g / 4, g & 3);
             if (g < 8) { read_one(2 * g); read_one(2 * g + 1); }
             if (g == 8) calc_addr(ad_new, n_chunk, n_tap, bstage_n);          // step kt+2
-#if !(Y2_TABL & 4)
             if (g == 9 + (Y2T_DMA_EARLY ? -100 : 0)) issue_slot(c_tap, c_chunk + 1, kt + NSB - 1, bstage_i);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         bstage_i = bstage_i == NSB - 1 ? 0 : bstage_i + 1;

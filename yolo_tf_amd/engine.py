@@ -103,6 +103,8 @@ class Engine(object):
         self._has_l2 = any(op.get('l2') for op in graph.ops)                         # (only the YOLO v1 family's fully connected layers)
         self.dropout_masks = None    # {op name: uint8 mask}: fixed keep masks (parity tests); None = drawn on the device per step
         self.dropout_seed = int(seed) + 1
+        self.dropout_rank = 0        # data-parallel rank and global step (set by TrainSession): every replica draws its own masks, and a
+        self.dropout_step = 0        # resumed run continues the mask sequence instead of replaying it from the start
         self._dropout_calls = 0
         self._masks = {}
         self._phase = 'fwd'          # 'fwd' | 'dgrad': which sweep a conv launch belongs to (timer tag)
@@ -487,7 +489,7 @@ class Engine(object):
                 mask = self._dropout_mask(op, n)
                 fixed = self.dropout_masks is not None
                 self._dropout_calls += 1
-                ops.dropout(self.act[x][0], self.act[out][0], mask, n, op['keep_prob'], 0 if fixed else self.dropout_seed * 1000003 + self._dropout_calls)
+                ops.dropout(self.act[x][0], self.act[out][0], mask, n, op['keep_prob'], 0 if fixed else self._dropout_seed_for(op))
             elif kind == 'pool':
                 x, out = op['x'], op['out']
                 if x in self.fused_pool:
@@ -687,6 +689,15 @@ class Engine(object):
         if op.get('l2', 0.0) > 0.0:
             w = self.var[op['weights'].name]
             ops.l2_regularizer(w, self.gvar[op['weights'].name], w.numel(), op['l2'], self.reg_loss)
+
+    def _dropout_seed_for(self, op):
+        """Seed of one dropout draw: a hash of (engine seed, data-parallel rank, global step, dropout layer) -- independent masks per
+        replica like the reference's per-tower draws, and no replay of the sequence after a restart (never 0: 0 selects fixed masks)."""
+        idx = [o['name'] for o in self.graph.ops if o['kind'] == 'dropout'].index(op['name'])
+        h = (self.dropout_seed * 0x9E3779B97F4A7C15 + self.dropout_rank * 0xC2B2AE3D27D4EB4F + self.dropout_step * 0x165667B19E3779F9 + idx * 0xD6E8FEB86659FD93)
+        h &= (1 << 64) - 1
+        h ^= h >> 31
+        return (h % ((1 << 62) - 1)) + 1
 
     def _dropout_mask(self, op, n):
         if self.dropout_masks is not None:

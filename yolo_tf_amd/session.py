@@ -64,6 +64,8 @@ class TrainSession(object):
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
         self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb) if world_size > 1 else None
+        if world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            e.dropout_rank = torch.distributed.get_rank()
         self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
@@ -85,6 +87,7 @@ class TrainSession(object):
         """Gradients are final (all-reduced) on return unless ``defer_collectives``: then the buckets may still be on the wire
         and ``apply_gradients`` consumes them one by one (what ``step`` does)."""
         e, m = self.engine, self.model
+        e.dropout_step = self.global_step
         e.zero_grads()
         e.set_images(images, self.preprocess_mode)
         e.forward()

@@ -284,23 +284,34 @@ def latest_checkpoint(logdir):
     return best
 
 
-def restore(prefix, session=None, engine=None, exclude=None):
+def checkpoint_step(prefix):
+    """global step in a checkpoint prefix's name (``model.ckpt-<step>``), -1 when it has none."""
+    import re
+    m = re.search(r'model\.ckpt-(\d+)$', prefix or '')
+    return int(m.group(1)) if m else -1
+
+
+def restore(prefix, session=None, engine=None, exclude=None, variables_only=False):
     """Variables of a TF checkpoint into the engine by name (``slim.assign_from_checkpoint_fn(model_path, tf.global_variables())``,
     detect.py:104-106): every graph variable found in the file is assigned; ``global_step`` and Adam's ``<var>/Adam``,
-    ``<var>/Adam_1`` slots go into a TrainSession when one is given.  Returns global_step (0 when absent)."""
+    ``<var>/Adam_1`` slots go into a TrainSession when one is given.  ``variables_only`` (the reference's ``-t ckpt -e scope...``
+    transfer, train.py:114,130-136): no optimizer slots, and ``global_step`` is taken unless ``exclude`` names it -- as
+    slim.get_variables_to_restore(exclude=...) does, so exponential_decay continues from the donor's step (checkpoint.restore
+    behaves the same).  Returns global_step (0 when absent)."""
     engine = engine if engine is not None else session.engine
     index = read_index(prefix)
     index.pop('', None)
     wanted = [v.name for v in engine.graph.variables.values() if v.name in index and not (exclude and any(v.name.startswith(s) for s in exclude))]
     extra = ['global_step'] if 'global_step' in index else []
     slots = []
-    if session is not None and session.optimizer.name == 'adam':
+    if session is not None and session.optimizer.name == 'adam' and not variables_only:
         slots = [n + sfx for n in wanted for sfx in ('/Adam', '/Adam_1') if n + sfx in index]
     values = read(prefix, set(wanted + extra + slots))
     engine.set_variables({k: values[k] for k in wanted}, strict=False)
     step = int(values['global_step']) if 'global_step' in values else 0
     if session is not None:
-        session.global_step = step
+        if not (variables_only and exclude and any('global_step'.startswith(s) for s in exclude)):
+            session.global_step = step
         if slots:
             import torch
             for n in wanted:
@@ -312,9 +323,10 @@ def restore(prefix, session=None, engine=None, exclude=None):
     return step
 
 
-def save(logdir, session, step=None):
+def save(logdir, session, step=None, keep=5):
     """Writes ``<logdir>/model.ckpt-<step>`` (+ the ``checkpoint`` state file) with the reference's variable names, global_step and
-    the Adam slots, i.e. what its tf.train.Saver would hold for this model."""
+    the Adam slots, i.e. what its tf.train.Saver would hold for this model.  Keeps the ``keep`` most recent checkpoints
+    ([TF-sem] tf.train.Saver max_to_keep=5: each is ~0.8 GB with Adam slots) and lists them in all_model_checkpoint_paths."""
     e = session.engine
     step = session.global_step if step is None else step
     tensors = dict(e.get_variables())
@@ -327,6 +339,18 @@ def save(logdir, session, step=None):
                 tensors[v.name + sfx] = host[o:o + sz].reshape(v.shape)
     prefix = os.path.join(logdir, 'model.ckpt-%d' % step)
     write(prefix, tensors)
+    import glob
+    found = sorted((checkpoint_step(q[:-len('.index')]), q[:-len('.index')]) for q in glob.glob(os.path.join(logdir, 'model.ckpt-*.index')))
+    found = [f for f in found if f[0] >= 0]
+    if keep and keep > 0:
+        kept = [f for f in found if f[1] == prefix or f in found[-keep:]]
+        for f in found:
+            if f not in kept:
+                for path in glob.glob(f[1] + '.index') + glob.glob(f[1] + '.data-*'):
+                    os.remove(path)
+        found = kept
     with open(os.path.join(logdir, 'checkpoint'), 'w') as f:
-        f.write('model_checkpoint_path: "model.ckpt-%d"\nall_model_checkpoint_paths: "model.ckpt-%d"\n' % (step, step))
+        f.write('model_checkpoint_path: "model.ckpt-%d"\n' % step)
+        for st, _ in found:
+            f.write('all_model_checkpoint_paths: "model.ckpt-%d"\n' % st)
     return prefix
