@@ -229,6 +229,7 @@ def main():
     ap.add_argument('--multiscale', action='store_true', help='BASELINE configs[3]: a different input size {320..608} every step (batch defaults to 8 per GPU)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--grad-dtype', default=None, choices=['f32', 'bf16'], help='wire format of the gradient all-reduce (N > 1); default: [mi355x] grad_dtype')
     ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
     args = ap.parse_args()
 
@@ -262,8 +263,9 @@ def main():
     if args.multiscale:
         return multiscale(args, rank, world, basedir, dist)
     builder, cfg = make_builder('darknet', args.names, args.size, True, basedir)
+    grad_dtype = args.grad_dtype or (cfg.get('mi355x', 'grad_dtype') if cfg.has_option('mi355x', 'grad_dtype') else 'f32')
     sess = TrainSession(builder, args.batch, dtype=args.dtype, optimizer='adam', learning_rate=1e-6, seed=0, world_size=world,
-                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'))
+                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'), grad_dtype=grad_dtype)
     cells = args.size // 32
     gen = torch.Generator(device='cuda').manual_seed(1234 + rank)
     images = torch.rand(args.batch, args.size, args.size, 3, device='cuda', generator=gen) * 255.0
@@ -303,10 +305,19 @@ def main():
         timer.enabled = False
         timer.calibrate()
         sess.engine.overlap_wgrad = overlap
+    comm_report = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-bucket collective and EXPOSED time (how long the optimizer's stream waited for each bucket), from a few instrumented steps
+        # after the timed region: makes the first multi-GPU run diagnosable (which bucket is not hidden behind backward / the update)
+        sess.reducer.timing = True
+        for _ in range(3):
+            sess.step(images)
+        torch.cuda.synchronize()
+        comm_report = sess.reducer.exposed_times()
+        sess.reducer.timing = False
     loss = sess.fetch()
 
     if rank == 0:
@@ -322,12 +333,17 @@ def main():
                                    % ('VOC' if args.names == 20 else 'COCO', args.names, args.size, args.size, args.batch,
                                       'BASELINE configs[2]' if (strong and args.names == 80) else 'BASELINE configs[1]' if (args.names == 20 and args.batch == 16) else 'variant'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)',
-                       'collective': ('RCCL all-reduce (%s), %d ranks, %d buckets' % (dist.get_backend(), dist.get_world_size(), len(sess.reducer.buckets)))
+                       'collective': ('RCCL all-reduce (%s, %s gradients), %d ranks, %d buckets' % (dist.get_backend(), grad_dtype, dist.get_world_size(), len(sess.reducer.buckets)))
                        if world > 1 else 'none (1 rank)'},
             'whole_step_tflops': value * gflop / 1e3,
             'whole_step_frac_of_mfma_peak': value * gflop / 1e3 / peak / world,
             'total_loss': loss['total_loss'],
         }
+        if comm_report is not None:
+            from yolo_tf_amd import ops as _ops
+            out['comm'] = {'grad_dtype': grad_dtype, 'buckets': comm_report, 'exposed_ms_per_step': sum(b['exposed_ms'] or 0.0 for b in comm_report),
+                           'stream_k_workgroups': _ops.get_stream_workgroups(),
+                           'note': 'rank 0, last of 3 instrumented steps after the timed region; exposed = time the update stream waited for the bucket'}
         ks = timer.summary(('fwd', 'dgrad')) if timer else None       # the 3x3 launches of the implicit-GEMM kernel
         if ks:
             kf, kd, k1 = timer.summary('fwd'), timer.summary('dgrad'), timer.summary('1x1')
@@ -398,10 +414,19 @@ def multiscale(args, rank, world, basedir, dist):
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    comm_report = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per-bucket collective and EXPOSED time (how long the optimizer's stream waited for each bucket), from a few instrumented steps
+        # after the timed region: makes the first multi-GPU run diagnosable (which bucket is not hidden behind backward / the update)
+        sess.reducer.timing = True
+        for _ in range(3):
+            sess.step(images)
+        torch.cuda.synchronize()
+        comm_report = sess.reducer.exposed_times()
+        sess.reducer.timing = False
     loss = sess.fetch()
     if rank == 0:
         gflop = sum(TRAIN_GFLOP_PER_IMG[args.names] * (sizes[i % len(sizes)] / 416.0) ** 2 for i in range(args.steps)) * batch * world

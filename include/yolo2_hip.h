@@ -410,6 +410,19 @@ int yolo2_transform_labels(const int *objects_class, const float *objects_coord,
                            float *prob, float *coords, float *offset_xy_min, float *offset_xy_max, float *areas, int B,
                            int classes, int cell_width, int cell_height, int *error_flag, void *stream);
 
+/* ---- data-parallel support (new work: the reference has no multi-GPU path, README.md:99).  The collectives themselves run in
+ * torch.distributed (RCCL); the library only provides what has to happen on the device around them. */
+/* Stream-K convolution launches use n workgroups instead of one per CU (0 = default): a data-parallel process leaves the CUs an
+ * RCCL ring occupies to it.  Process-wide; never affects results. */
+int yolo2_set_stream_workgroups(int n);
+int yolo2_get_stream_workgroups(void);
+/* gradient wire format: round an f32 range to bf16 / widen it back (16-byte aligned pointers) */
+int yolo2_cast_f32_bf16(const float *src, void *dst, long n, void *stream);
+int yolo2_cast_bf16_f32(const void *src, float *dst, long n, void *stream);
+/* test instrument: `workgroups` persistent workgroups, one whole CU each (160 KiB LDS), until *stop != 0 or max_us have passed;
+ * *started counts the resident ones (what a collective's persistent kernels look like to the dispatcher) */
+int yolo2_debug_occupy(int workgroups, int *stop, int *started, int max_us, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,6 +98,20 @@ def _worker(rank, world, port, out):
     assert seen == red.buckets
     # folded averaging: the optimizer's gscale = 1/world turns the sum into the mean
     assert torch.allclose(grads / world, torch.arange(off, dtype=torch.float32) * (world + 1) / 2)
+    # bf16 wire format (half the bytes per link): the same bucket protocol; each rank's contribution is rounded to bf16, the sum is
+    # formed in bf16 and widened back into the f32 arena -- equal on every rank, within bf16 rounding of the exact sum
+    g2 = (torch.arange(off, dtype=torch.float32) * 0.37 + 1.0) * (rank + 1)
+    red16 = GradReducer(g2, offs, bucket_mb=300 * 4 / (1024 * 1024), grad_dtype='bf16')
+    assert red16.wire.dtype == torch.bfloat16 and red16.buckets == red.buckets
+    red16.begin()
+    red16.finish(wait=False)
+    for lo, hi in red16.completed_buckets():
+        exact = (torch.arange(lo, hi, dtype=torch.float32) * 0.37 + 1.0) * sum(range(1, world + 1))
+        assert torch.all((g2[lo:hi] - exact).abs() <= 2 ** -7 * exact.abs()), (rank, lo, hi)
+        assert torch.equal(g2[lo:hi], g2[lo:hi].to(torch.bfloat16).float())          # what arrived is a bf16 value
+    gathered = [torch.empty_like(g2) for _ in range(world)]
+    dist.all_gather(gathered, g2)
+    assert all(torch.equal(gathered[0], t) for t in gathered)                        # replicas see identical gradients
     if rank == 0:
         open(out, 'w').write('ok')
     dist.barrier()

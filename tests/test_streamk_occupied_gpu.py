@@ -1,0 +1,102 @@
+"""Stream-K convolutions beside persistent kernels of another stream (VERDICT r2 item 10 / next #5a).
+
+In a data-parallel step an RCCL ring holds one persistent workgroup per channel for the whole collective, on a high-priority stream,
+while backward keeps launching stream-K convolutions (exactly one workgroup per CU, owners spinning on hand-off flags).  No multi-GPU
+node is available to the tests, so the dispatcher sees the same thing from `yolo2_debug_occupy`: N persistent 256-thread workgroups
+that own a whole CU each (160 KiB of LDS) until a flag is raised (bounded by a timeout inside the kernel: the GPU cannot hang on it).
+
+Checked, for the conv18 / conv20 shapes of the bench (forward and data gradient, tap-fused and per-tap stream-K):
+  * liveness: the convolution FINISHES while the occupier is still resident (owners only wait for parked tails, and a tail is the
+    first thing its workgroup does -- so a grid that is only partly resident drains),
+  * correctness: the result equals the un-occupied run bit for bit up to the stream-K summation order,
+  * the data-parallel sizing (yolo2_set_stream_workgroups(CUs - reserve)) launches exactly that many workgroups and gives the same result."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_kernels_gpu import assert_close, bf16_round, dev, host   # noqa: E402
+
+SHAPES = [(16, 13, 13, 1024, 1024, 'conv18 forward / data gradient'), (16, 13, 13, 3072, 1024, 'conv20 forward'), (16, 13, 13, 1024, 3072, 'conv20 data gradient'),
+          (16, 13, 13, 512, 1024, 'conv13 forward (per-tap stream-K)')]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from yolo_tf_amd import ops as _ops
+    _ops._lib.load()
+    return _ops
+
+
+@pytest.mark.parametrize('occupied', [32, 64])
+@pytest.mark.parametrize('shape', SHAPES)
+def test_stream_k_beside_persistent_workgroups(ops, shape, occupied):
+    B, H, W, Cin, Cout, _ = shape
+    k, M = 3, B * H * W
+    rng = np.random.RandomState(Cin + Cout + occupied)
+    T = torch.bfloat16
+    x = dev(bf16_round(rng.randn(B, H, W, Cin).astype(np.float32)), T)
+    w = (rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32)
+    F = torch.zeros(Cout * k * k * Cin, dtype=T, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, Cout, T)
+    ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+
+    def conv():
+        O = torch.zeros(M * Cout, dtype=T, device='cuda')
+        ops.conv2d_ws(x, F, None, O, ws, B, H, W, Cin, Cin, Cout, Cout, k)
+        return O, ops.last_conv_plan()
+
+    ref, plan = conv()
+    torch.cuda.synchronize()
+    assert plan['split'] == 2 and plan['grid_x'] == cus, plan            # stream-K, one workgroup per CU
+    # ---- beside `occupied` persistent workgroups on a high-priority stream
+    stop = torch.zeros(1, dtype=torch.int32, device='cuda')
+    started = torch.zeros(1, dtype=torch.int32, device='cuda')
+    side = torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(side):
+        ops.debug_occupy(occupied, stop, started, 300000)               # at most 0.3 s, whatever happens
+    t0 = time.time()
+    while int(started.item()) < occupied and time.time() - t0 < 5:      # (.item() synchronises the default stream only)
+        time.sleep(0.001)
+    assert int(started.item()) == occupied, 'the occupier is not resident'
+    done = torch.cuda.Event()
+    got, plan2 = conv()
+    done.record()
+    t1 = time.time()
+    while not done.query() and time.time() - t1 < 0.25:
+        time.sleep(0.0005)
+    finished_while_occupied = done.query() and not side.query()
+    stop.fill_(1)                                                        # release the occupier (it also times out on its own)
+    torch.cuda.synchronize()
+    assert finished_while_occupied, 'stream-K did not finish on %d free CUs while %d were held' % (cus - occupied, occupied)
+    assert plan2['grid_x'] == cus
+    assert_close(host(got), host(ref), 8e-3, 'occupied vs free')
+    assert float((got.float() - ref.float()).abs().max()) <= 8e-3 * float(ref.float().abs().max())
+    # ---- the data-parallel sizing: CUs - reserve workgroups
+    ops.set_stream_workgroups(cus - occupied)
+    try:
+        assert ops.get_stream_workgroups() == cus - occupied
+        got2, plan3 = conv()
+        torch.cuda.synchronize()
+        assert plan3['split'] == 2 and plan3['grid_x'] == cus - occupied, plan3
+        assert_close(host(got2), host(ref), 8e-3, 'capped vs default')
+    finally:
+        ops.set_stream_workgroups(0)
+    assert ops.get_stream_workgroups() == cus
+
+
+def test_gradient_wire_casts(ops):
+    n = 1000003
+    src = torch.randn(n + 5, device='cuda')[:n]
+    src = src.clone()
+    wire = torch.zeros(n, dtype=torch.bfloat16, device='cuda')
+    back = torch.zeros(n, device='cuda')
+    ops.cast_f32_bf16(src, wire, n)
+    ops.cast_bf16_f32(wire, back, n)
+    torch.cuda.synchronize()
+    assert torch.equal(wire, src.to(torch.bfloat16))                     # round-to-nearest-even, as the hardware conversion
+    assert torch.equal(back, wire.float())

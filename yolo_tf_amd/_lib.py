@@ -83,6 +83,10 @@ SIGNATURES = {
     'yolo2_zero_ranges': [_p, _p, _i, _p],
     'yolo2_bn_fold': [_p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _p],
     'yolo2_selftest_tr16': [_p, _p],
+    'yolo2_set_stream_workgroups': [_i],
+    'yolo2_cast_f32_bf16': [_p, _p, _l, _p],
+    'yolo2_cast_bf16_f32': [_p, _p, _l, _p],
+    'yolo2_debug_occupy': [_i, _p, _p, _i, _p],
 }
 
 # host queries / diagnostics: (restype, argtypes); bound in load() next to the status-returning entries above
@@ -94,6 +98,7 @@ QUERIES = {
     'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
     'yolo2_debug_set_wgrad_variant': (None, [_i]),
     'yolo2_last_bn_part_rows': (_i, []),
+    'yolo2_get_stream_workgroups': (_i, []),
     'yolo2_bn_fin_supported': (_i, [_i, _i, _i]),
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_set_igemm_tap': (_i, [_i]),

@@ -1138,6 +1138,28 @@ extern "C" int yolo2_debug_set_igemm_tap(int on) {
     return YOLO2_OK;
 }
 
+// Stream-K launches take exactly one workgroup per CU.  A process that shares the GPU with persistent kernels of another stream -- an
+// RCCL ring holds one workgroup per channel for the whole collective -- would get a second, mostly idle wave of workgroups on the CUs
+// that are left; yolo2_set_stream_workgroups(n) (data-parallel sessions: CUs - [mi355x] comm_cus) sizes the launches for the CUs that
+// are free.  0 restores the default (all CUs, or YOLO2_IGEMM_STREAM_WGS).  Correctness never depends on the value: owners only wait
+// for parked tails, and a tail is the first thing its workgroup does (deadlock-free under any residency; tests/test_streamk_occupied_gpu.py).
+static std::atomic<int> g_stream_wgs{0};
+extern "C" int yolo2_set_stream_workgroups(int n) {
+    if (n < 0 || n > Y2_STREAM_FLAG_WORDS) { yolo2_set_error("yolo2_set_stream_workgroups: 0 (default) .. %d", Y2_STREAM_FLAG_WORDS); return YOLO2_E_ARG; }
+    g_stream_wgs.store(n, std::memory_order_relaxed);
+    return YOLO2_OK;
+}
+extern "C" int yolo2_get_stream_workgroups(void) {
+    const int n = g_stream_wgs.load(std::memory_order_relaxed);
+    return n > 0 ? n : tune().cus;
+}
+static Tune tune_now() {
+    Tune t = tune();
+    const int n = g_stream_wgs.load(std::memory_order_relaxed);
+    if (n > 0) { t.cus = n; if (!getenv("YOLO2_IGEMM_STREAM_MAXTILES")) t.stream_max_tiles = 3 * n; }
+    return t;
+}
+
 template <typename T>
 static int launch_conv(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H, int W,
                        int Cp, int ldp, int Nf, int ldo, int ksize, hipStream_t st, const float *bn_shift, float *bn_part, bool *stats_done, float act_alpha,
@@ -1146,7 +1168,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     const int MT = cdiv(M, 128);
     constexpr int VEC = 16 / sizeof(T);
     constexpr int BK = 4 * VEC;
-    const Tune &tu = tune();
+    const Tune tu = tune_now();
     const unsigned p_bytes = (unsigned)((size_t)M * ldp * sizeof(T));
     const unsigned f_bytes = (unsigned)((size_t)Nf * ksize * ksize * Cp * sizeof(T));
     const bool ctail = (Cp % BK) != 0;

@@ -1850,3 +1850,73 @@ extern "C" int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const vo
     *rows = nb;
     return YOLO2_OK;
 }
+
+// ---- gradient wire format of the data-parallel exchange (parallel.GradReducer, grad_dtype = bf16): the f32 gradient bucket is rounded
+// to bf16 into a wire buffer, all-reduced there (half the xGMI bytes: 134 MB instead of 269 MB per step and rank), and widened back into
+// the f32 arena the optimizer reads.  16 bytes per lane on the wide side.
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float *__restrict__ src, bf16 *__restrict__ dst, long n) {
+    const long nv = n >> 3, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        const f32x4 a = reinterpret_cast<const f32x4 *>(src)[2 * i], b = reinterpret_cast<const f32x4 *>(src)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = (bf16)a[j]; o[4 + j] = (bf16)b[j]; }
+        reinterpret_cast<bf16x8 *>(dst)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = (bf16)src[(nv << 3) + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16 *__restrict__ src, float *__restrict__ dst, long n) {
+    const long nv = n >> 3, stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+        const bf16x8 v = reinterpret_cast<const bf16x8 *>(src)[i];
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = (float)v[j]; b[j] = (float)v[4 + j]; }
+        reinterpret_cast<f32x4 *>(dst)[2 * i] = a;
+        reinterpret_cast<f32x4 *>(dst)[2 * i + 1] = b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = (float)src[(nv << 3) + threadIdx.x];
+}
+extern "C" int yolo2_cast_f32_bf16(const float *src, void *dst, long n, void *stream) {
+    Y2_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+    if (n == 0) return YOLO2_OK;
+    cast_f32_bf16_kernel<<<ew_grid((n + 7) / 8), 256, 0, (hipStream_t)stream>>>(src, (bf16 *)dst, n);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_cast_bf16_f32(const void *src, float *dst, long n, void *stream) {
+    Y2_CHECK_ARG(src && dst && n >= 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0);
+    if (n == 0) return YOLO2_OK;
+    cast_bf16_f32_kernel<<<ew_grid((n + 7) / 8), 256, 0, (hipStream_t)stream>>>((const bf16 *)src, dst, n);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ---- test instrument: what an RCCL ring looks like to the dispatcher.  `workgroups` persistent 256-thread workgroups, each holding a
+// whole CU (all 160 KiB of LDS), spin until *stop becomes non-zero or `max_us` microseconds have passed (bounded: a test can never hang
+// the GPU on it).  *started counts the workgroups that are resident.  tests/test_streamk_occupied_gpu.py runs the stream-K convolutions
+// beside it.
+__global__ __launch_bounds__(256) void occupy_kernel(volatile int *stop, int *started, long max_ticks) {
+    extern __shared__ unsigned char lds[];
+    if (threadIdx.x == 0) {
+        lds[0] = 1;
+        __hip_atomic_fetch_add(started, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long t0 = wall_clock64();
+        while (__hip_atomic_load(const_cast<int *>(stop), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(32);
+    }
+    __syncthreads();
+}
+extern "C" int yolo2_debug_occupy(int workgroups, int *stop, int *started, int max_us, void *stream) {
+    Y2_CHECK_ARG(workgroups > 0 && workgroups <= 256 && stop && started && max_us > 0 && max_us <= 2000000);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            yolo2_set_error("yolo2_debug_occupy: cannot raise the dynamic LDS limit");
+            return YOLO2_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    occupy_kernel<<<workgroups, 256, 160 * 1024, (hipStream_t)stream>>>(stop, started, (long)max_us * 100);      // wall_clock64 ticks at 100 MHz
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}

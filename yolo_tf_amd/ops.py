@@ -357,3 +357,25 @@ def dropout_bwd(dY, mask, dX, n, keep_prob):
 
 def l2_regularizer(w, g, n, scale, loss):
     call('yolo2_l2_regularizer', ptr(w), ptr(g), n, scale, ptr(loss), _stream())
+
+
+# ---- data-parallel support
+def set_stream_workgroups(n):
+    """Stream-K convolution launches use ``n`` workgroups instead of one per CU (0 = default)."""
+    call('yolo2_set_stream_workgroups', int(n))
+
+
+def get_stream_workgroups():
+    return int(_lib.load().yolo2_get_stream_workgroups())
+
+
+def cast_f32_bf16(src, dst, n):
+    call('yolo2_cast_f32_bf16', ptr(src), ptr(dst), n, _stream())
+
+
+def cast_bf16_f32(src, dst, n):
+    call('yolo2_cast_bf16_f32', ptr(src), ptr(dst), n, _stream())
+
+
+def debug_occupy(workgroups, stop, started, max_us):
+    call('yolo2_debug_occupy', workgroups, ptr(stop), ptr(started), max_us, _stream())

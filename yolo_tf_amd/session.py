@@ -23,7 +23,7 @@ class TrainSession(object):
     per-tensor clip -> optimizer; all asynchronous on the current stream."""
 
     def __init__(self, builder, batch_size, dtype='bf16', optimizer='adam', learning_rate=1e-6, gradient_clip=0.0,
-                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None):
+                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None, grad_dtype='f32', comm_cus=None, comm_timing=False):
         """``sizes``: optional list of (width, height) input sizes for multi-scale training (BASELINE configs[3]); buffers are
         allocated once for the largest, ``set_size`` switches between them, the builder's configured size is selected first."""
         assert builder.training, 'call builder(data, training=True) first'
@@ -63,7 +63,14 @@ class TrainSession(object):
         self.global_step = 0
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
-        self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb) if world_size > 1 else None
+        self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb, grad_dtype=grad_dtype, timing=comm_timing) if world_size > 1 else None
+        if world_size > 1:
+            # the collectives' persistent kernels hold CUs for their whole duration: stream-K launches (one workgroup per CU) are sized
+            # for what is left ([mi355x] comm_cus, default 32 -- an RCCL ring's channel count on this part)
+            cfg = config if config is not None else builder.config
+            reserve = comm_cus if comm_cus is not None else (cfg.getint('mi355x', 'comm_cus') if cfg is not None and cfg.has_option('mi355x', 'comm_cus') else 32)
+            total = torch.cuda.get_device_properties(dev).multi_processor_count
+            ops.set_stream_workgroups(max(64, total - int(reserve)) if reserve > 0 else 0)
         if world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
             e.dropout_rank = torch.distributed.get_rank()
         self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
