@@ -120,6 +120,15 @@ typedef struct yolo2_filter_desc {
 int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype,
                             void *stream);
 
+/* tf.train.AdamOptimizer's ApplyAdam (train.py:73-79,127) over every convolution filter of the descriptor table AND the operand layouts
+ * of the updated filters, in one pass: equal, bit for bit, to yolo2_adam on the same elements followed by yolo2_filter_prep_batch.
+ * descs[i].W must point into `params`; grads / m / v are arenas with the same element layout.  small_ranges_device: n_small pairs
+ * (element offset, count) of the parameters that are not filters (gamma, beta, biases), updated by the same launch.  alpha is the
+ * bias-corrected step size (lr * sqrt(1 - beta2^t) / (1 - beta1^t)), gscale multiplies the gradient (1 / world size). */
+int yolo2_adam_filter_prep(const yolo2_filter_desc *descs_device, int n, int total_blocks, const long *small_ranges_device, int n_small,
+                           float *params, const float *grads, float *m, float *v, float alpha, float beta1, float beta2, float eps,
+                           float gscale, int dtype, void *stream);
+
 /* Inference form of a batch-normalised layer with the moving statistics folded into the operands
  * (W' = W * gamma/sqrt(var+eps) per output channel, bias' = beta - mean*gamma/sqrt(var+eps)):
  *   O = leaky_relu(conv(P, F') + bias', alpha)      -- conv + batch_norm(is_training=False) + leaky_relu of

@@ -458,6 +458,62 @@ def test_filter_prep_batch_matches_per_layer(ops):
             assert torch.equal(ff, ef) and torch.equal(fd, ed)
 
 
+def test_adam_fused_with_filter_prep_is_bit_identical(ops):
+    """yolo2_adam_filter_prep == yolo2_adam over the arena followed by yolo2_filter_prep_batch, bit for bit (parameters, both Adam slots,
+    both operand layouts), including the non-filter parameter ranges and the 16-byte alignment gaps (never touched); and the Adam
+    arithmetic itself against the oracle."""
+    from yolo_tf_amd._lib import FilterDesc
+    rng = np.random.RandomState(4)
+    layers = [(3, 3, 32), (3, 32, 64), (1, 128, 64), (3, 40, 125), (1, 1024, 125), (3, 128, 192)]
+    # arena: per layer [filter][gamma-like range of cout][3 floats of padding]
+    offs, off = [], 0
+    for k, cin, cout in layers:
+        offs.append((off, k * k * cin * cout, off + (k * k * cin * cout + 3) // 4 * 4, cout))
+        off = offs[-1][2] + (cout + 3) // 4 * 4 + 4
+    n = off
+    hyper = dict(alpha=1e-3 * np.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3), b1=0.9, b2=0.999, eps=1e-8, gscale=0.5)
+    for tdtype in (torch.float32, torch.bfloat16):
+        p0 = rng.randn(n).astype(np.float32)
+        g0, m0, v0 = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32) * 0.1, (rng.rand(n) * 0.01).astype(np.float32)
+        res = {}
+        for fused in (False, True):
+            P, G, M_, V = dev(p0), dev(g0), dev(m0), dev(v0)
+            arr = (FilterDesc * len(layers))()
+            keep, first, small = [], 0, []
+            for d, (k, cin, cout), (o, sz, o2, n2) in zip(arr, layers, offs):
+                ldcin, ldcout = ops.pad8(cin), ops.pad8(cout)
+                ff = torch.full((cout * k * k * ldcin,), 3.0, dtype=tdtype, device='cuda')
+                fd = torch.full((cin * k * k * ldcout,), 3.0, dtype=tdtype, device='cuda')
+                d.W, d.Ffwd, d.Fdgr = P[o:].data_ptr(), ff.data_ptr(), fd.data_ptr()
+                d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, cin, ldcin, cout, ldcout, first
+                first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+                keep.append((ff, fd))
+                small += [o2, n2]
+            descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+            if fused:
+                ops.adam_filter_prep(descs, len(layers), first, torch.tensor(small, dtype=torch.int64, device='cuda'), len(layers), P, G, M_, V,
+                                     hyper['alpha'], hyper['b1'], hyper['b2'], hyper['eps'], hyper['gscale'], tdtype)
+            else:
+                for o, sz, o2, n2 in offs:         # the plain kernel over exactly the same elements
+                    ops.adam(P[o:], G[o:], M_[o:], V[o:], sz, hyper['alpha'], hyper['b1'], hyper['b2'], hyper['eps'], hyper['gscale'])
+                    ops.adam(P[o2:], G[o2:], M_[o2:], V[o2:], n2, hyper['alpha'], hyper['b1'], hyper['b2'], hyper['eps'], hyper['gscale'])
+                ops.filter_prep_batch(descs, len(layers), first, tdtype)
+            torch.cuda.synchronize()
+            res[fused] = (P, M_, V, keep)
+        for what, a, b in zip(('params', 'm', 'v'), res[False][:3], res[True][:3]):
+            assert torch.equal(a, b), (what, float((a - b).abs().max()), int((a != b).sum()))
+        for (ff0, fd0), (ff1, fd1) in zip(res[False][3], res[True][3]):
+            assert torch.equal(ff0, ff1) and torch.equal(fd0, fd1)
+        touched = np.zeros(n, bool)
+        for o, sz, o2, n2 in offs:
+            touched[o:o + sz] = True
+            touched[o2:o2 + n2] = True
+        assert np.array_equal(host(res[True][0])[~touched], p0[~touched])           # alignment gaps untouched
+        w_ref, m_ref, v_ref = R.adam_step(p0[touched], g0[touched] * np.float32(hyper['gscale']), m0[touched], v0[touched], 1e-3, 3)
+        assert np.allclose(host(res[True][0])[touched], w_ref, rtol=2e-6, atol=1e-7)
+        assert np.allclose(host(res[True][1])[touched], m_ref, rtol=2e-6, atol=1e-8) and np.allclose(host(res[True][2])[touched], v_ref, rtol=2e-6, atol=1e-10)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 26, 26, 32), (1, 52, 48, 64), (3, 8, 6, 8), (2, 14, 14, 512), (1, 4, 4, 1024)])
 def test_bn_leaky_pool_fused_equals_unfused(ops, shape, mode):

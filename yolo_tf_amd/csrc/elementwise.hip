@@ -1412,6 +1412,9 @@ extern "C" int yolo2_image_prep(const float *img, void *out, double *ws, int B, 
 // the dominant optimizer: 28 B of HBM traffic per parameter.  16-byte accesses when the four arenas are 16-byte aligned
 // (they are: the engine's arenas and every all-reduce bucket start on a multiple of 4 elements), scalar tail otherwise.
 __device__ __forceinline__ void adam_one(float &w, float g, float &m, float &v, float alpha, float omb1, float omb2, float eps, float gs) {
+    // no FMA contraction: the update is inlined into several kernels (adam_kernel, adam_filter_prep_kernel) whose results must agree bit
+    // for bit, and separate multiplies / adds are what the oracle (and TF's Eigen expression) evaluates
+#pragma clang fp contract(off)
     const float gi = g * gs;
     const float mi = m + (gi - m) * omb1;
     const float vi = v + (gi * gi - v) * omb2;
@@ -1917,6 +1920,114 @@ extern "C" int yolo2_debug_occupy(int workgroups, int *stop, int *started, int m
         attr_set = true;
     }
     occupy_kernel<<<workgroups, 256, 160 * 1024, (hipStream_t)stream>>>(stop, started, (long)max_us * 100);      // wall_clock64 ticks at 100 MHz
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// ---- Adam + operand layouts in one pass (round 3).  The Adam kernel streams every weight through registers anyway; the operand
+// re-layout (filter_prep_batch_kernel: 268 MB re-read of the f32 masters + one more launch per step) rides on it: a workgroup takes one
+// 64 x 64 (c, n) tile of one tap of one layer -- the re-layout's own decomposition, which covers every filter element exactly once --
+// updates w / m / v in place (16-byte accesses, the same arithmetic as adam_kernel) and emits both bf16 / f32 operand layouts from the
+// fresh values staged in LDS.  The parameters that are not convolution filters (gamma, beta, biases: ~22 k floats in 43 ranges) are
+// updated by the extra workgroups at the end of the grid.  Results are bit-identical to yolo2_adam followed by yolo2_filter_prep_batch.
+struct Y2AdamArgs { float *params; const float *grads; float *m, *v; float alpha, omb1, omb2, eps, gs; };
+template <typename T>
+__global__ __launch_bounds__(256) void adam_filter_prep_kernel(const yolo2_filter_desc *__restrict__ descs, int n, int conv_blocks,
+                                                               const long *__restrict__ small, const Y2AdamArgs a) {
+    if ((int)blockIdx.x >= conv_blocks) {      // a non-filter parameter range [small[2i], small[2i] + small[2i+1])
+        const long *r = small + 2 * ((int)blockIdx.x - conv_blocks);
+        for (long k = threadIdx.x; k < r[1]; k += 256) {
+            const long o = r[0] + k;
+            adam_one(a.params[o], a.grads[o], a.m[o], a.v[o], a.alpha, a.omb1, a.omb2, a.eps, a.gs);
+        }
+        return;
+    }
+    constexpr int TS = YOLO2_FILTER_PREP_TILE;
+    __shared__ float tile[TS][TS + 1];
+    int li = 0;
+    while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].first_block) ++li;
+    const yolo2_filter_desc d = descs[li];
+    const int taps = d.ksize * d.ksize;
+    const int ctiles = (d.ldcin + TS - 1) / TS, ntiles = (d.ldcout + TS - 1) / TS;
+    int u = blockIdx.x - d.first_block;
+    const int ntile = u % ntiles; u /= ntiles;
+    const int ctile = u % ctiles;
+    const int tap = u / ctiles;
+    const int n0 = ntile * TS, c0 = ctile * TS;
+    const int tid = threadIdx.x;
+    const long base = (d.W - a.params) + (long)tap * d.cin * d.cout;       // element offset of this tap's [cin][cout] plane in the arenas
+    const bool vec_ok = (d.cout & 3) == 0 && ((base & 3) == 0);
+    {
+        const int col = (tid & 15) * 4, r0 = tid >> 4;
+#pragma unroll
+        for (int p = 0; p < TS / 16; ++p) {
+            const int c = c0 + r0 + p * 16, nn = n0 + col;
+            float w4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (c < d.cin) {
+                const long o = base + (long)c * d.cout + nn;
+                if (vec_ok && nn + 3 < d.cout) {
+                    f32x4 wv = *reinterpret_cast<const f32x4 *>(a.params + o), mv = *reinterpret_cast<const f32x4 *>(a.m + o), vv = *reinterpret_cast<const f32x4 *>(a.v + o);
+                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(a.grads + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float wj = wv[j], mj = mv[j], vj = vv[j];
+                        adam_one(wj, gv[j], mj, vj, a.alpha, a.omb1, a.omb2, a.eps, a.gs);
+                        wv[j] = wj; mv[j] = mj; vv[j] = vj; w4[j] = wj;
+                    }
+                    *reinterpret_cast<f32x4 *>(a.m + o) = mv;
+                    *reinterpret_cast<f32x4 *>(a.v + o) = vv;
+                    *reinterpret_cast<f32x4 *>(a.params + o) = wv;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (nn + j < d.cout) {
+                            adam_one(a.params[o + j], a.grads[o + j], a.m[o + j], a.v[o + j], a.alpha, a.omb1, a.omb2, a.eps, a.gs);
+                            w4[j] = a.params[o + j];
+                        }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[r0 + p * 16][col + j] = w4[j];
+        }
+    }
+    __syncthreads();
+    T *Ff = (T *)d.Ffwd, *Fd = (T *)d.Fdgr;
+    const int g8 = (tid & 7) * 8, rr = tid >> 3;
+    if (Ff) {
+        const long Kf = (long)taps * d.ldcin;
+#pragma unroll
+        for (int p = 0; p < TS / 32; ++p) {
+            const int nl = rr + p * 32, nn = n0 + nl, c = c0 + g8;
+            if (nn < d.cout && c < d.ldcin) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[g8 + j][nl];
+                store8<T>(Ff + nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps), v);
+            }
+        }
+    }
+    if (Fd) {
+        const long Kd = (long)taps * d.ldcout;
+        const int tp = taps - 1 - tap;
+#pragma unroll
+        for (int p = 0; p < TS / 32; ++p) {
+            const int cl = rr + p * 32, c = c0 + cl, nn = n0 + g8;
+            if (c < d.cin && nn < d.ldcout) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[cl][g8 + j];
+                store8<T>(Fd + c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps), v);
+            }
+        }
+    }
+}
+extern "C" int yolo2_adam_filter_prep(const yolo2_filter_desc *descs_device, int n, int total_blocks, const long *small_ranges_device, int n_small,
+                                      float *params, const float *grads, float *m, float *v, float alpha, float beta1, float beta2, float eps,
+                                      float gscale, int dtype, void *stream) {
+    Y2_CHECK_ARG(descs_device && n > 0 && total_blocks > 0 && n_small >= 0 && (small_ranges_device || n_small == 0) && params && grads && m && v);
+    Y2_CHECK_ARG(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0);
+    const Y2AdamArgs a{params, grads, m, v, alpha, 1.0f - beta1, 1.0f - beta2, eps, gscale};
+    Y2_DISPATCH_DTYPE(dtype, adam_filter_prep_kernel<T><<<total_blocks + n_small, 256, 0, (hipStream_t)stream>>>(descs_device, n, total_blocks, small_ranges_device, a));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

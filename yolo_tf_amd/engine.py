@@ -338,33 +338,50 @@ class Engine(object):
         """HWIO f32 masters -> both MFMA operand layouts of every layer, one launch (descriptor table built once)."""
         if not self._filters_dirty:
             return
-        if getattr(self, '_fdesc', None) is None:
-            import ctypes
-            from ._lib import FilterDesc
-            convs = [op for op in self.graph.ops if op['kind'] == 'conv']
-            arr = (FilterDesc * len(convs))()
-            first = 0
-            for d, op in zip(arr, convs):
-                st = self.conv[op['name']]
-                k, ldcin, ldcout = op['ksize'], pad8(op['cin']), pad8(op['cout'])
-                if self._folds(op):
-                    # inference: moving statistics folded into the filter (W * gamma/sigma) and a bias (beta - mean*gamma/sigma)
-                    st['fold_w'] = torch.empty_like(self.var[op['weights'].name])
-                    st['fold_bias'] = torch.empty(op['cout'], dtype=torch.float32, device=self.device)
-                d.W = (st['fold_w'] if 'fold_w' in st else self.var[op['weights'].name]).data_ptr()
-                d.Ffwd = st['Ffwd'].data_ptr()
-                d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
-                d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
-                first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
-            raw = bytes(arr)
-            self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._fdesc_n, self._fdesc_blocks = len(convs), first
+        self._filter_descs()
         for op in self.graph.ops:
             if op['kind'] == 'conv' and 'fold_w' in self.conv[op['name']]:
                 st = self.conv[op['name']]
                 ops.bn_fold(self.var[op['weights'].name], self.var[op['gamma'].name], self.var[op['beta'].name], self.var[op['moving_mean'].name],
                             self.var[op['moving_variance'].name], st['fold_w'], st['fold_bias'], op['ksize'] ** 2 * op['cin'], op['cout'], BN_EPS)
         ops.filter_prep_batch(self._fdesc, self._fdesc_n, self._fdesc_blocks, self.dtype)
+        self._filters_dirty = False
+
+    def _filter_descs(self):
+        """Device table of yolo2_filter_desc (one per convolution, built once) + the non-filter parameter ranges of the arena."""
+        if getattr(self, '_fdesc', None) is not None:
+            return
+        from ._lib import FilterDesc
+        convs = [op for op in self.graph.ops if op['kind'] == 'conv']
+        arr = (FilterDesc * len(convs))()
+        first = 0
+        for d, op in zip(arr, convs):
+            st = self.conv[op['name']]
+            k, ldcin, ldcout = op['ksize'], pad8(op['cin']), pad8(op['cout'])
+            if self._folds(op):
+                # inference: moving statistics folded into the filter (W * gamma/sigma) and a bias (beta - mean*gamma/sigma)
+                st['fold_w'] = torch.empty_like(self.var[op['weights'].name])
+                st['fold_bias'] = torch.empty(op['cout'], dtype=torch.float32, device=self.device)
+            d.W = (st['fold_w'] if 'fold_w' in st else self.var[op['weights'].name]).data_ptr()
+            d.Ffwd = st['Ffwd'].data_ptr()
+            d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
+            d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
+            first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+        raw = bytes(arr)
+        self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self._fdesc_n, self._fdesc_blocks = len(convs), first
+        covered = sorted(self.param_offsets[op['weights'].name] for op in self.graph.ops if op['kind'] == 'conv')
+        small = sorted(v for k, v in self.param_offsets.items() if v not in covered)
+        flat = [x for o, n in small for x in (o, n)]
+        self._small = torch.tensor(flat if flat else [0, 0], dtype=torch.int64, device=self.device)
+        self._n_small = len(small)
+
+    def adam_update_and_prepare(self, m, v, alpha, beta1, beta2, eps, gscale):
+        """Adam over the whole arena + both operand layouts of every filter in ONE launch (yolo2_adam_filter_prep); the next forward
+        finds its filters prepared."""
+        self._filter_descs()
+        ops.adam_filter_prep(self._fdesc, self._fdesc_n, self._fdesc_blocks, self._small, self._n_small, self.params, self.grads, m, v,
+                             alpha, beta1, beta2, eps, gscale, self.dtype)
         self._filters_dirty = False
 
     def _folds(self, op):

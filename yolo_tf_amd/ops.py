@@ -69,6 +69,11 @@ def filter_prep_batch(descs_dev, n, total_blocks, dtype):
     call('yolo2_filter_prep_batch', ptr(descs_dev), n, total_blocks, dtype_code(dtype), _stream())
 
 
+def adam_filter_prep(descs_dev, n, total_blocks, small_dev, n_small, params, grads, m, v, alpha, b1, b2, eps, gscale, dtype):
+    call('yolo2_adam_filter_prep', ptr(descs_dev), n, total_blocks, ptr(small_dev), n_small, ptr(params), ptr(grads), ptr(m), ptr(v), alpha, b1, b2, eps, gscale,
+         dtype_code(dtype), _stream())
+
+
 def bn_stats(Y, mean, var, ws, M, C):
     call('yolo2_bn_stats', ptr(Y), ptr(mean), ptr(var), ptr(ws), M, C, dtype_code(Y.dtype), _stream())
 

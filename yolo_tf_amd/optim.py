@@ -60,6 +60,14 @@ class Optimizer(object):
             'gd': lambda: [],
         }[name]()
 
+    def apply_fused_with_filter_prep(self, engine, lr, t, gscale=1.0):
+        """Adam over the whole arena and the operand layouts of the updated filters in one launch (engine.adam_update_and_prepare);
+        bit-identical to ``apply`` followed by the engine's filter preparation."""
+        assert self.name == 'adam'
+        hp = self.hp
+        alpha = lr * math.sqrt(1.0 - hp['beta2'] ** t) / (1.0 - hp['beta1'] ** t)
+        engine.adam_update_and_prepare(self.slots[0], self.slots[1], alpha, hp['beta1'], hp['beta2'], hp['epsilon'], gscale)
+
     def apply(self, params, grads, lr, t, gscale=1.0, lo=0, hi=None):
         """t = 1-based update count (Adam bias correction).  [lo, hi) restricts the update to a slice of the flat arenas
         (data parallel: one call per all-reduce bucket as the buckets arrive)."""

@@ -74,6 +74,7 @@ class TrainSession(object):
         if world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
             e.dropout_rank = torch.distributed.get_rank()
         self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
+        self.fuse_adam_prep = os.environ.get('YOLO2_FUSE_ADAM_PREP', '1') != '0'      # A/B: 0 = Adam launch + separate operand re-layout at the next forward
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
 
@@ -132,10 +133,16 @@ class TrainSession(object):
             for lo, hi in self.reducer.completed_buckets():
                 self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale, lo, hi)
             self._deferred = False
+            self.global_step += 1
+            e._filters_dirty = True
+        elif self.optimizer.name == 'adam' and self.fuse_adam_prep:
+            # Adam + the operand layouts of the updated filters in one launch: the next forward finds its filters prepared
+            self.optimizer.apply_fused_with_filter_prep(e, lr, self.global_step + 1, gscale)
+            self.global_step += 1
         else:
             self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale)
-        self.global_step += 1
-        e._filters_dirty = True
+            self.global_step += 1
+            e._filters_dirty = True
 
     def step(self, images, labels=None):
         if labels is not None:
