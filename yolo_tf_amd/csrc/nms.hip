@@ -4,16 +4,21 @@
 // One workgroup per (image, class).  The reference's `boxes.sort(key=conf[c], reverse=True)` is a
 // STABLE sort applied to the list order left by the previous class, so the effective key of class
 // c is lexicographic (conf[:,c] desc, conf[:,c-1] desc, ..., conf[:,0] desc, box index asc) on the
-// ORIGINAL scores -- which makes every class independent.  Phase 1 ranks the N boxes with that
-// comparator (rank = number of boxes that sort before me; O(N^2/256) per thread from LDS
-// broadcasts).  Phase 2 is the greedy scan, done by ONE wavefront: for each surviving box above
-// the threshold, every lane tests one sorted position per 64-box chunk and __ballot() turns the
-// 64 IoU compares into one 64-bit word of the overlap bitmask that is OR-ed into the chunk's
-// `removed` word (kept in the lane that owns the chunk).  IoU is evaluated in fp32 in the
+// ORIGINAL scores -- which makes every class independent.  Phase 1 sorts the boxes with that
+// comparator: a bitonic network over box indices in LDS (round 3; the first version counted, for every
+// box, the boxes that sort before it -- O(N^2/256) comparisons per thread, 11 % of a sparse batch-256
+// detect for the one class whose full order is observable).  Phase 2 is the greedy scan, 64 candidates
+// (boxes above the threshold, in sorted order) at a time: all four waves build the group's rows of the
+// overlap bitmask -- every lane tests one sorted position per 64-box chunk and __ballot() turns the 64
+// IoU compares into one 64-bit word -- and one wave then walks the group, OR-ing the rows of the
+// candidates that are still alive into the `removed` words (kept in the lane that owns the chunk): the
+// serial part is one LDS row per candidate instead of an IoU loop (the first version's whole scan ran on
+// one wavefront: 4.9 ms of a dense batch-256 detect).  IoU is evaluated in fp32 in the
 // reference's operation order ((a1+a2)-inter, floor 1e-10, `>=`) with FP contraction off.
 // Finally the removed boxes' scores in column c are zeroed in place, as the reference mutates
 // its input.
 #include "common.h"
+#include <stdlib.h>
 #pragma clang fp contract(off)
 
 __device__ __forceinline__ bool sorts_before(const float *__restrict__ conf0, long jrow, long irow, int j, int i, int c, int C, float kj, float ki) {
@@ -25,18 +30,23 @@ __device__ __forceinline__ bool sorts_before(const float *__restrict__ conf0, lo
     return j < i;
 }
 
+#define Y2_NMS_GROUP 64      // candidates whose overlap rows are built together (one sorted 64-box chunk)
 __global__ __launch_bounds__(256) void nms_kernel(float *__restrict__ conf, const float *__restrict__ conf0, const float *__restrict__ xy_min,
                                                   const float *__restrict__ xy_max, int *__restrict__ order_out, int N, int C,
-                                                  float thr, float thr_iou) {
+                                                  float thr, float thr_iou, int NP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float *key = reinterpret_cast<float *>(smem_raw);      // [N] original scores of this class (box order)
     float *skey = key + N;                                  // [N] scores in sorted order
     int *sidx = reinterpret_cast<int *>(skey + N);          // [N] sorted position -> box index
     f32x4 *sbox = reinterpret_cast<f32x4 *>(sidx + N + ((4 - (3 * N) % 4) % 4));  // [N] (minx,miny,maxx,maxy), 16-B aligned
+    int *perm = reinterpret_cast<int *>(sbox + N);          // [NP] box indices being sorted (-1 = padding, sorts last); NP = pow2 >= N
+    int *cnt = perm + NP;                                   // [256] candidates per thread range
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(cnt + 256);      // [Y2_NMS_GROUP][nchunks] overlap words of one candidate group
 
     const int b = blockIdx.x / C, c = blockIdx.x % C;
     const long base = (long)b * N;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunks = (N + 63) >> 6;           // <= 64 (N <= 4096)
 
     for (int i = tid; i < N; i += 256) key[i] = conf0[(base + i) * C + c];
     __syncthreads();
@@ -48,84 +58,99 @@ __global__ __launch_bounds__(256) void nms_kernel(float *__restrict__ conf, cons
         bx[2] = xy_max[(base + i) * 2]; bx[3] = xy_max[(base + i) * 2 + 1];
         sbox[rank] = bx;
     };
-    // The exact order of the boxes at or below the threshold never matters to the scan (they cannot suppress, and they all
-    // sort after every box that can), so only the K boxes above it are ranked -- K^2 instead of N^2 comparisons (the full
-    // sort was 19 % of a batch-256 detect).  The complete order is still produced where it is observable: for the class
-    // whose order is reported (order_out), and for negative thresholds.
+    // bitonic network on perm[0..np): the comparator is a strict total order (ties end at the box index), so the result is THE sorted
+    // sequence whatever the network's exchange order
+    auto bitonic = [&](int np) {
+        for (int k = 2; k <= np; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                __syncthreads();
+                for (int t = tid; t < (np >> 1); t += 256) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                    const int a = perm[i], bb = perm[l];
+                    // which of the two belongs first?  padding (-1) belongs after everything
+                    const bool b_first = bb >= 0 && (a < 0 || sorts_before(conf0, base + bb, base + a, bb, a, c, C, key[bb], key[a]));
+                    const bool up = (i & k) == 0;          // ascending block: the element that sorts first takes the lower position
+                    if (up == b_first && (a >= 0 || bb >= 0)) { perm[i] = bb; perm[l] = a; }
+                }
+            }
+        __syncthreads();
+    };
+    // candidates = boxes above the threshold: only they can suppress, and they all sort before every other box.  The exact order of
+    // the others never matters to the scan, so only the K candidates are sorted; the complete order is still produced where it is
+    // observable: for the class whose order is reported (order_out), and for negative thresholds.
+    const int per = (N + 255) / 256;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    int nc = 0;
+    for (int i = lo; i < hi; ++i) nc += key[i] > thr ? 1 : 0;
+    cnt[tid] = nc;
+    __syncthreads();
+    int before = 0, K = 0;
+    for (int t = 0; t < 256; ++t) {
+        const int v = cnt[t];
+        before += t < tid ? v : 0;
+        K += v;
+    }
     const bool full = !(0.0f <= thr) || (order_out && c == C - 1);
     if (full) {
-        for (int i = tid; i < N; i += 256) {
-            const float ki = key[i];
-            int rank = 0;
-            for (int j = 0; j < N; ++j) rank += sorts_before(conf0, base + j, base + i, j, i, c, C, key[j], ki) ? 1 : 0;
-            place(rank, i);
-        }
+        for (int i = tid; i < NP; i += 256) perm[i] = i < N ? i : -1;
+        bitonic(NP);
+        for (int p = tid; p < N; p += 256) place(p, perm[p]);
+        if (!(0.0f <= thr)) K = N;               // negative threshold: every box is a candidate (the scan below tests the current score)
     } else {
-        int *cidx = reinterpret_cast<int *>(sbox + N);       // [N] box indices of the candidates, in box order
-        int *cnt = cidx + N;                                  // [256] candidates per thread range
-        const int per = (N + 255) / 256;
-        const int lo = min(tid * per, N), hi = min(lo + per, N);
-        int nc = 0;
-        for (int i = lo; i < hi; ++i) nc += key[i] > thr ? 1 : 0;
-        cnt[tid] = nc;
-        __syncthreads();
-        int before = 0, K = 0;
-        for (int t = 0; t < 256; ++t) {
-            const int v = cnt[t];
-            before += t < tid ? v : 0;
-            K += v;
-        }
-        int ci = before, ni = K + (lo - before);             // candidates keep box order in cidx; the others fill positions K..N-1
+        int np = 1;
+        while (np < K) np <<= 1;
+        for (int i = K + tid; i < np; i += 256) perm[i] = -1;
+        int ci = before, ni = K + (lo - before);             // candidates keep box order in perm; the others fill positions K..N-1
         for (int i = lo; i < hi; ++i) {
-            if (key[i] > thr) cidx[ci++] = i;
+            if (key[i] > thr) perm[ci++] = i;
             else place(ni++, i);
         }
-        __syncthreads();
-        for (int q = tid; q < K; q += 256) {
-            const int i = cidx[q];
-            const float ki = key[i];
-            int rank = 0;
-            for (int r = 0; r < K; ++r) {
-                const int j = cidx[r];
-                rank += sorts_before(conf0, base + j, base + i, j, i, c, C, key[j], ki) ? 1 : 0;
-            }
-            place(rank, i);
-        }
+        bitonic(np);
+        for (int p = tid; p < K; p += 256) place(p, perm[p]);
     }
     __syncthreads();
     if (c == C - 1 && order_out)
         for (int p = tid; p < N; p += 256) order_out[base + p] = sidx[p];
-    if (tid >= 64) return;
 
-    // ---- greedy scan by one wavefront ----
-    const int lane = tid;
-    const int nchunks = (N + 63) >> 6;           // <= 64 (N <= 4096)
-    unsigned long long myword = 0ull;            // lane k owns the `removed` word of chunk k
-    for (int p = 0; p + 1 < N; ++p) {
-        const float kp = skey[p];
-        if (kp <= thr && 0.0f <= thr) break;     // sorted descending: nothing later can suppress
-        const unsigned long long wp = __shfl(myword, p >> 6, 64);
-        const bool removed = (wp >> (p & 63)) & 1ull;
-        const float cur = removed ? 0.0f : kp;
-        if (cur <= thr) continue;                // utils/postprocess.py:46-47
-        const f32x4 bp = sbox[p];
-        const float a1 = (bp[2] - bp[0]) * (bp[3] - bp[1]);
-        for (int k = p >> 6; k < nchunks; ++k) {
-            const int pos = (k << 6) + lane;
-            bool hit = false;
-            if (pos > p && pos < N) {
-                const f32x4 bq = sbox[pos];
-                const float a2 = (bq[2] - bq[0]) * (bq[3] - bq[1]);
-                const float w = fmaxf(fminf(bp[2], bq[2]) - fmaxf(bp[0], bq[0]), 0.0f);
-                const float h = fmaxf(fminf(bp[3], bq[3]) - fmaxf(bp[1], bq[1]), 0.0f);
-                const float inter = w * h;
-                const float iou = inter / fmaxf((a1 + a2) - inter, 1e-10f);
-                hit = iou >= thr_iou;             // :49
+    // ---- greedy scan.  Per group of 64 candidates: all four waves build the group's overlap rows (row p, word k = which of the boxes
+    // 64k .. 64k+63 candidate p suppresses: one __ballot per word; independent of what has been removed so far), then ONE wave walks
+    // the group in order, OR-ing the rows of the candidates that are still alive into the `removed` words (lane k owns chunk k).
+    // IoU in the reference's operation order ((a1+a2)-inter, floor 1e-10, `>=`), FP contraction off.
+    unsigned long long myword = 0ull;
+    for (int g0 = 0; g0 < K && g0 + 1 < N; g0 += Y2_NMS_GROUP) {
+        const int gend = min(g0 + Y2_NMS_GROUP, K);
+        for (int p = g0 + wave; p < gend; p += 4) {
+            const f32x4 bp = sbox[p];
+            const float a1 = (bp[2] - bp[0]) * (bp[3] - bp[1]);
+            for (int k = g0 >> 6; k < nchunks; ++k) {
+                const int pos = (k << 6) + lane;
+                bool hit = false;
+                if (pos > p && pos < N) {
+                    const f32x4 bq = sbox[pos];
+                    const float a2 = (bq[2] - bq[0]) * (bq[3] - bq[1]);
+                    const float w = fmaxf(fminf(bp[2], bq[2]) - fmaxf(bp[0], bq[0]), 0.0f);
+                    const float h = fmaxf(fminf(bp[3], bq[3]) - fmaxf(bp[1], bq[1]), 0.0f);
+                    const float inter = w * h;
+                    const float iou = inter / fmaxf((a1 + a2) - inter, 1e-10f);
+                    hit = iou >= thr_iou;             // utils/postprocess.py:49
+                }
+                const unsigned long long word = __ballot(hit);
+                if (lane == 0) rows[(p - g0) * nchunks + k] = word;
             }
-            const unsigned long long word = __ballot(hit);
-            if (lane == k) myword |= word;
         }
+        __syncthreads();
+        if (wave == 0) {
+            for (int p = g0; p < gend && p + 1 < N; ++p) {
+                const unsigned long long wp = __shfl(myword, p >> 6, 64);
+                const bool removed = (wp >> (p & 63)) & 1ull;
+                const float cur = removed ? 0.0f : skey[p];
+                if (cur <= thr) continue;                // utils/postprocess.py:46-47 (a suppressed box has score 0)
+                if (lane >= (g0 >> 6) && lane < nchunks) myword |= rows[(p - g0) * nchunks + lane];
+            }
+        }
+        __syncthreads();
     }
+    if (wave != 0) return;
     for (int k = 0; k < nchunks; ++k) {
         const unsigned long long word = __shfl(myword, k, 64);
         const int pos = (k << 6) + lane;
@@ -144,13 +169,19 @@ extern "C" int yolo2_nms(float *conf, const float *xy_min, const float *xy_max, 
         yolo2_set_error("nms: snapshot copy failed");
         return YOLO2_E_LAUNCH;
     }
-    const size_t lds = sizeof(float) * 3 * (size_t)N + 16 + sizeof(float) * 4 * (size_t)N + sizeof(int) * ((size_t)N + 256);
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        yolo2_set_error("nms: cannot reserve %zu bytes of LDS", lds);
-        return YOLO2_E_LAUNCH;
+    int NP = 2;                       // (even: keeps the 8-byte words behind perm[] aligned)
+    while (NP < N) NP <<= 1;
+    const size_t nchunks = ((size_t)N + 63) / 64;
+    const size_t lds = sizeof(float) * 3 * (size_t)N + 16 + sizeof(float) * 4 * (size_t)N + sizeof(int) * ((size_t)NP + 256) + 8 * (64 * nchunks + 1);
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        if (hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            yolo2_set_error("nms: cannot reserve %zu bytes of LDS", lds);
+            return YOLO2_E_LAUNCH;
+        }
+        lds_set = lds;
     }
-    nms_kernel<<<B * C, 256, lds, st>>>(conf, (const float *)ws, xy_min, xy_max, order_out, N, C, threshold, threshold_iou);
+    nms_kernel<<<B * C, 256, lds, st>>>(conf, (const float *)ws, xy_min, xy_max, order_out, N, C, threshold, threshold_iou, NP);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
