@@ -597,7 +597,7 @@ template <bool BNBWD, int HROWS, int NSB>
 __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
     const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate) {
     typedef bf16 T;
     constexpr int BM = Y2T_BM, BN = Y2T_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
     constexpr int HBYTES = HROWS * 128, ZERO = 2 * HBYTES + NSB * Y2T_BBYTES, HPIECES = HROWS / 8, HSLOTS = (HPIECES + NW - 1) / NW;
@@ -614,6 +614,18 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
     const int wx = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
     long su = wx * su_total / G;
     const long su_end = (wx + 1) * su_total / G;
+    // K rotation (round 3).  A tile's K steps are shared by P ~ nk / share consecutive workgroups, and the workgroups of an XCD all work
+    // on the same filter tile's slab (BN x K: 7 MB on the 3072-channel layer, more than the 4 MB L2).  With every tile starting at K
+    // step 0, the j-th workgroup enters its tile at offset (j * share) mod nk, which drifts by P * share - nk per tile: the ~32
+    // workgroups of an XCD sit at ~32 different K positions and each of the 11 pixel tiles re-streams the slab from the fabric
+    // (814 MB fetched for 79 MB of operands, profiles/r02_hbm_traffic_pmc.md row 70).  The sum over K does not care where it starts:
+    // tile t processes its chunks in the cyclic order (c + rot_t) mod nch with rot_t cancelling the drift, so the workgroups holding the
+    // first / second / third share of their tiles all read the same slab bytes at the same time and the L2 serves all but one of them.
+    // Ownership, parking and the flat (tile, step) bookkeeping are untouched: only the chunk -> memory offset mapping rotates.
+    const int nch = Cp / 64;
+    const double share = (double)su_total / (double)G;
+    const int shares_per_tile = (int)((double)nk / share + 0.5);
+    const double drift_chunks = k_rotate && shares_per_tile >= 2 ? ((double)shares_per_tile * share - (double)nk) / (double)TAPS : 0.0;
 
     const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
@@ -634,6 +646,14 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
     const int nt = t / MT, mt = t - nt * MT;
     if (!first_seg) __syncthreads();                     // every wave is done with the previous segment's LDS
     const int m0 = mt * BM, n0 = nt * BN;
+    int rot;                                             // this tile's chunk rotation, 0 <= rot < nch
+    {
+        const long r = (long)__builtin_floor(-(double)t * drift_chunks + 0.5);
+        rot = (int)(r % nch);
+        if (rot < 0) rot += nch;
+        rot = __builtin_amdgcn_readfirstlane(rot);
+    }
+    auto mem_chunk = [&](int c) { const int m = c + rot; return m >= nch ? m - nch : m; };      // logical chunk (0 <= c <= nch) -> chunk in memory
 
     // halo DMA descriptor: slot j of this wave is piece j * 8 + wave = halo rows 8 * piece .. + 7 (pieces >= HPIECES do not exist).  Rows
     // before pixel 0 wrap to offsets >= 2^31 and rows past the last pixel lie beyond num_records: both read as zeros; slot j is slot
@@ -682,12 +702,12 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
         {
             const bool real = hs >= 0 && hs < HSLOTS && hs * NW + wave < HPIECES && hc * TAPS < kt_end;
             unsigned char *dst = real ? smem + (hc & 1) * HBYTES + (hs * NW + wave) * 1024 : zero;
-            const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)hc * 128u : Y2_OOB;
+            const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)mem_chunk(hc) * 128u : Y2_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
         }
         const bool breal = kb < kt_end;
         const int bc = kb / TAPS, bt = kb - bc * TAPS;
-        const unsigned offB = (unsigned)(bc * TAPS * 64 + bt * 64) * 2u;
+        const unsigned offB = (unsigned)(mem_chunk(bc) * TAPS * 64 + bt * 64) * 2u;
         unsigned char *Bs = smem + 2 * HBYTES + bstage * Y2T_BBYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -748,13 +768,13 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
         for (int j = 0; j < HSLOTS; ++j) {
             const bool real = j * NW + wave < HPIECES;
             unsigned char *dst = real ? smem + (c_chunk & 1) * HBYTES + (j * NW + wave) * 1024 : zero;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)c_chunk * 128u : Y2_OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_chunk) * 128u : Y2_OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < HSLOTS; ++j) {           // slots 0 .. c_tap-1 of the NEXT chunk's halo would have been issued by now
             const bool real = j < c_tap && j * NW + wave < HPIECES && (c_chunk + 1) * TAPS < kt_end;
             unsigned char *dst = real ? smem + ((c_chunk + 1) & 1) * HBYTES + (j * NW + wave) * 1024 : zero;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)(c_chunk + 1) * 128u : Y2_OOB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_chunk + 1) * 128u : Y2_OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int d = 0; d < NSB - 1; ++d) issue_slot(-1, 0, kt_beg + d, d);
@@ -1200,9 +1220,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 9, 2, tu.cus, 1};      // "stages" 9: nine taps per halo image
             for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
             const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4);
+            static const int k_rotate = getenv("YOLO2_IGEMM_TAP_ROTATE") ? atoi(getenv("YOLO2_IGEMM_TAP_ROTATE")) : 1;       // A/B: 0 = every tile starts at K step 0
 #define Y2T_LAUNCH(BWDv, HRv, NSBv)                                                                                                      \
             conv3x3_tap_kernel<BWDv, HRv, NSBv><<<dim3(tu.cus), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
-                                                                              H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_)
+                                                                              H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_, k_rotate)
             if (W <= 27) { if (bz.Y) Y2T_LAUNCH(true, 312, 5); else Y2T_LAUNCH(false, 312, 5); }
             else { if (bz.Y) Y2T_LAUNCH(true, 368, 4); else Y2T_LAUNCH(false, 368, 4); }
 #undef Y2T_LAUNCH

@@ -75,17 +75,34 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     const int tgroups = PAIR ? (taps + 1) / 2 : taps;         // tile rows along the tap axis
     const int ntiles = tgroups * CT * NT;
     int bx, by;
-    if (remap) {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        by = (idx / ntiles) * 8 + xcd;
-        bx = idx % ntiles;
+    int nt, ct, tgi;                                           // filter tile, channel tile, tap (group) index
+    if (remap == 2) {
+        // ONE pixel range (the tile grid alone covers the chip: 13x13 stages).  Every tile then streams the whole X column tile and dY
+        // filter tile, so what the XCD's L2 can share is decided by the ORDER of the tiles: XCD x (blocks b % 8 == x) takes a contiguous
+        // run of tiles in the order (channel tile, filter tile, tap) with the tap fastest -- the nine taps of a (ct, nt) pair run together
+        // and read the same X and dY bytes at the same time, and an XCD works through few channel tiles (conv20: 3 of 24, 2 MB of X).
+        // With the plain order (filter tile fastest, tap slowest) every XCD re-fetched all of X once per tap: 778 MB of fabric traffic
+        // for 22 MB of operands on the 3072-channel layer (profiles/r02_hbm_traffic_pmc.md row 83).
+        const int ntile = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = ntile >> 3, r = ntile & 7;
+        int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;       // bijective for any grid size
+        tgi = t % tgroups; t /= tgroups;
+        nt = t % NT;
+        ct = t / NT;
+        by = 0;
     } else {
-        bx = blockIdx.x % ntiles;
-        by = blockIdx.x / ntiles;
+        if (remap) {
+            const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+            by = (idx / ntiles) * 8 + xcd;
+            bx = idx % ntiles;
+        } else {
+            bx = blockIdx.x % ntiles;
+            by = blockIdx.x / ntiles;
+        }
+        nt = bx % NT; bx /= NT;
+        ct = bx % CT;
+        tgi = bx / CT;
     }
-    const int nt = bx % NT; bx /= NT;
-    const int ct = bx % CT;
-    const int tap = PAIR ? 2 * (bx / CT) : bx / CT;            // PAIR: first tap of the pair
+    const int tap = PAIR ? 2 * tgi : tgi;                      // PAIR: first tap of the pair
     const int pad = ksize >> 1;
     const int dh = tap / ksize - pad, dw = tap % ksize - pad;
     const int tap2 = tap + 1;                                  // PAIR: second tap (may not exist: taps is odd)
@@ -395,14 +412,15 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     // a tile grid that already covers the chip takes ONE pixel range: no atomics, plain stores (measured: the atomic epilogue
     // of a 2-way split costs more than the second workgroup per tile gains)
     static const int direct_min = getenv("YOLO2_WGRAD_DIRECT_MIN_TILES") ? atoi(getenv("YOLO2_WGRAD_DIRECT_MIN_TILES")) : 256;
-    if (direct_min > 0 && p.tiles >= direct_min) { ks = 1; remap = 0; }
+    static const int single_order = getenv("YOLO2_WGRAD_SINGLE_ORDER") ? atoi(getenv("YOLO2_WGRAD_SINGLE_ORDER")) : 1;       // A/B: 0 = plain tile order
+    if (direct_min > 0 && p.tiles >= direct_min) { ks = 1; remap = single_order ? 2 : 0; }
     if (ks < 1) ks = 1;
     p.mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
     ks = cdiv(M, p.mchunk);
-    if (remap && ks % 8 != 0) remap = (ks >= 8);              // rounding may have changed the count; ragged tail is fine
+    if (remap == 1 && ks % 8 != 0) remap = (ks >= 8);         // rounding may have changed the count; ragged tail is fine
     p.ks = ks;
     p.remap = remap;
-    p.blocks = remap ? p.tiles * (cdiv(ks, 8) * 8) : p.tiles * ks;
+    p.blocks = remap == 1 ? p.tiles * (cdiv(ks, 8) * 8) : p.tiles * ks;
     return p;
 }
 
