@@ -394,8 +394,19 @@ def _dp_worker(rank, world, port, outdir):
     params1 = e.params.clone()
     sess.step(images)                                   # the production path: buckets consumed by the optimizer as they arrive
     torch.cuda.synchronize()
+    params2 = e.params.clone()
+    # the bf16 wire format + per-bucket timing (what `bench.py --gpus N --grad-dtype bf16` runs): the cast kernels and the collective on
+    # the communication stream, two ranks; replicas must stay identical and the report has one entry per bucket
+    from yolo_tf_amd.parallel import GradReducer
+    from yolo_tf_amd import ops
+    assert ops.get_stream_workgroups() == max(64, torch.cuda.get_device_properties(0).multi_processor_count - 32)      # CUs left to the collective
+    sess.reducer = GradReducer(e.grads, list(e.param_offsets.values()), 8.0, grad_dtype='bf16', timing=True)
+    sess.step(images)
+    torch.cuda.synchronize()
+    rep = sess.reducer.exposed_times()
+    assert len(rep) == len(sess.reducer.buckets) and all(r['collective_ms'] > 0 and r['exposed_ms'] >= 0 for r in rep)
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), local=local.cpu().numpy(), summed=summed.cpu().numpy(), params=params1.cpu().numpy(),
-             params2=e.params.cpu().numpy())
+             params2=params2.cpu().numpy(), params3=e.params.cpu().numpy(), grads3=e.grads.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -416,6 +427,9 @@ def test_data_parallel_step_two_processes_one_gpu(tmp_path):
     assert np.abs(r0['summed'] - ref).max() <= 1e-5 * np.abs(ref).max()      # f32 atomics: order-dependent rounding only
     np.testing.assert_array_equal(r0['params'], r1['params'])
     np.testing.assert_array_equal(r0['params2'], r1['params2'])                 # bucket-wise update: replicas still identical
+    np.testing.assert_array_equal(r0['params3'], r1['params3'])                 # ... and with the bf16 wire format
+    np.testing.assert_array_equal(r0['grads3'], r1['grads3'])
+    assert np.array_equal(r0['grads3'], torch.from_numpy(r0['grads3']).to(torch.bfloat16).float().numpy())     # what arrived are bf16 values
     assert np.abs(r0['params2'] - r0['params']).max() > 0
     assert np.abs(r0['local'] - r1['local']).max() > 0                          # the ranks really saw different data
 
