@@ -275,7 +275,7 @@ int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, in
 /* ---- input: tf.image.per_image_standardization train.py:103 / utils/preprocess.py:23-25 --------
  * img: f32 [B,H,W,3] (0..255); out: dtype [B,H,W,8] (channels 3..7 zero).
  * mode 0: (x-mean)/max(std,1/sqrt(N)) per image; mode 1: x/255 (detect.py:37-38);
- * mode 2: plain cast.  ws: >= 2*B doubles. */
+ * mode 2: plain cast.  ws: yolo2_image_prep_workspace_bytes(B) (mode 0: 64 partial (sum, sum of squares) pairs per image; any content). */
 int yolo2_image_prep(const float *img, void *out, double *ws, int B, int HW, int mode, int dtype,
                      void *stream);
 
@@ -304,6 +304,13 @@ int yolo2_loss(const void *logits, int ld, const float *anchors, const float *ma
                const float *prob, const float *coords, const float *off_min, const float *off_max,
                const float *areas, const float *hparam, float *objectives, void *dlogits,
                float *ws, int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream);
+/* yolo2_loss in two halves: the kernel that writes dlogits and per-workgroup partial sums into ws (all a training step needs), and the
+ * reduction of those partials into the four objective values, run only when they are read (summaries). */
+int yolo2_loss_partials(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
+                        const float *coords, const float *off_min, const float *off_max, const float *areas,
+                        const float *hparam, void *dlogits, float *ws, int B, int cell_h, int cell_w, int A, int C, int dtype,
+                        void *stream);
+int yolo2_loss_objectives(const float *ws, float *objectives, int B, int cell_h, int cell_w, int A, void *stream);
 
 /* ---- YOLO (v1) family, SURVEY 8f-4: model/yolo/__init__.py:37-100, model/yolo/inference.py:24-66 --------------------------
  * Network output row per image [cells*C class scores | cells*boxes*(iou, x, y, sqrt_w, sqrt_h)], all linear; `ld` = row stride.

@@ -40,7 +40,7 @@ def test_workspace_queries_are_host_only_and_match_the_documented_sizes():
     q = _lib.query
     assert q('yolo2_bn_workspace_bytes', 1024) == 1025 * 1024 * 8
     assert q('yolo2_bias_grad_workspace_bytes', 432) == 512 * 432 * 8
-    assert q('yolo2_image_prep_workspace_bytes', 16) == 2 * 16 * 8
+    assert q('yolo2_image_prep_workspace_bytes', 16) == 2 * 64 * 16 * 8        # 64 partial (sum, sum of squares) pairs per image
     assert q('yolo2_nms_workspace_bytes', 256, 845, 20) == 256 * 845 * 20 * 4
     assert q('yolo2_loss_workspace_bytes', 16, 169, 5) == (4 * ((16 * 169 * 8 + 255) // 256) + 4) * 4
     assert q('yolo2_clip_workspace_bytes', 66) == 66 * 8 and q('yolo2_augment_workspace_bytes', 16) == 3 * 16 * 8

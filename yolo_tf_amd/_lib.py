@@ -65,6 +65,8 @@ SIGNATURES = {
     'yolo2_head_decode': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_head_decode_attrs': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_loss': [_p, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_loss_partials': [_p, _i, _p, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_loss_objectives': [_p, _p, _i, _i, _i, _i, _p],
     'yolo1_loss': [_p, _i, _p, _p, _p, _p, _p, _p, ctypes.POINTER(_f), _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo1_head_decode': [_p, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_leaky_bwd': [_p, _p, _p, _l, _f, _i, _p],

@@ -1320,6 +1320,11 @@ extern "C" int yolo2_add_inplace(void *dst, const void *src, long n, int dtype, 
 // ------------------------------------------------------------------------------------------
 // image prep (tf.image.per_image_standardization, train.py:103; utils/preprocess.py:23-25)
 // ------------------------------------------------------------------------------------------
+// Two launches, no memset, no atomics (round 3; was memset + atomic sums + apply): every workgroup of the first kernel stores its (sum,
+// sum of squares) pair -- f64, 16-byte loads, four independent chains -- into ws[b][block][2]; the second kernel's workgroups each work
+// on ONE image and fold that image's Y2_IMG_PARTS partial pairs in their prologue (the finalisation rides in the consumer, as for the
+// batch-norm statistics).  The partial layout makes the result independent of scheduling: bit-reproducible run to run.
+#define Y2_IMG_PARTS 64
 __global__ __launch_bounds__(256) void image_sums_kernel(const float *__restrict__ img, double *__restrict__ ws, long n_per_image) {
     const int b = blockIdx.y;
     const float *p = img + (long)b * n_per_image;
@@ -1358,47 +1363,73 @@ __global__ __launch_bounds__(256) void image_sums_kernel(const float *__restrict
         s[0] += d;
         q[0] += d * d;
     }
+    __shared__ double red[2][4];
     const double st = wave_sum_d((s[0] + s[1]) + (s[2] + s[3]));
     const double qt = wave_sum_d((q[0] + q[1]) + (q[2] + q[3]));
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(ws + 2 * b, st);
-        atomicAdd(ws + 2 * b + 1, qt);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = st; red[1][threadIdx.x >> 6] = qt; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const double *r = red[threadIdx.x];
+        ws[((long)b * gridDim.x + blockIdx.x) * 2 + threadIdx.x] = (r[0] + r[1]) + (r[2] + r[3]);
     }
 }
+// grid = (blocks per image, B): the image index is blockIdx.y; parts = partial pairs per image left by image_sums_kernel (mode 0)
 template <typename T>
-__global__ void image_apply_kernel(const float *__restrict__ img, T *__restrict__ out, const double *__restrict__ ws, int B, long HW, int mode) {
-    const long total = (long)B * HW;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int b = (int)(i / HW);
-        float sub = 0.f, den = 1.f;
-        if (mode == 0) {
-            const double n = (double)HW * 3.0;
-            double mean = ws[2 * b] / n;
-            double var = ws[2 * b + 1] / n - mean * mean;
-            if (var < 0) var = 0;
-            sub = (float)mean;
-            den = fmaxf((float)sqrt(var), (float)(1.0 / sqrt(n)));
-        } else if (mode == 1) {
-            den = 255.0f;
-        }
-        const float *p = img + i * 3;
-        T *o = out + i * 8;
+__global__ __launch_bounds__(256) void image_apply_kernel(const float *__restrict__ img, T *__restrict__ out, const double *__restrict__ ws, long HW, int mode, int parts) {
+    const int b = blockIdx.y;
+    float sub = 0.f, den = 1.f;
+    if (mode == 0) {
+        __shared__ double red[2][4];
+        double a = 0.0, c = 0.0;
+        for (int k = threadIdx.x; k < parts; k += 256) { a += ws[((long)b * parts + k) * 2]; c += ws[((long)b * parts + k) * 2 + 1]; }
+        a = wave_sum_d(a);
+        c = wave_sum_d(c);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = c; }
+        __syncthreads();
+        const double sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), sq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double n = (double)HW * 3.0;
+        const double mean = sum / n;
+        double var = sq / n - mean * mean;
+        if (var < 0) var = 0;
+        sub = (float)mean;
+        den = fmaxf((float)sqrt(var), (float)(1.0 / sqrt(n)));
+    } else if (mode == 1) {
+        den = 255.0f;
+    }
+    const float *pi = img + (long)b * HW * 3;
+    T *po = out + (long)b * HW * 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) {
+        const float *p = pi + i * 3;
         float v0 = p[0], v1 = p[1], v2 = p[2];
         if (mode != 2) { v0 = (v0 - sub) / den; v1 = (v1 - sub) / den; v2 = (v2 - sub) / den; }
-        o[0] = (T)v0; o[1] = (T)v1; o[2] = (T)v2;
-        o[3] = (T)0.f; o[4] = (T)0.f; o[5] = (T)0.f; o[6] = (T)0.f; o[7] = (T)0.f;
+        Vec16<T> o[sizeof(T) == 2 ? 1 : 2];
+        if constexpr (sizeof(T) == 2) {
+            o[0].set(0, v0); o[0].set(1, v1); o[0].set(2, v2);
+#pragma unroll
+            for (int j = 3; j < 8; ++j) o[0].set(j, 0.f);
+            st16(po + i * 8, o[0]);
+        } else {
+            o[0].set(0, v0); o[0].set(1, v1); o[0].set(2, v2); o[0].set(3, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[1].set(j, 0.f);
+            st16(po + i * 8, o[0]);
+            st16(po + i * 8 + 4, o[1]);
+        }
     }
 }
 extern "C" int yolo2_image_prep(const float *img, void *out, double *ws, int B, int HW, int mode, int dtype, void *stream) {
-    Y2_CHECK_ARG(img && out && B > 0 && HW > 0 && mode >= 0 && mode <= 2);
+    Y2_CHECK_ARG(img && out && B > 0 && HW > 0 && mode >= 0 && mode <= 2 && ((uintptr_t)out & 15) == 0);
     hipStream_t st = (hipStream_t)stream;
+    int parts = 0;
     if (mode == 0) {
         Y2_CHECK_ARG(ws);
-        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * B, st) != hipSuccess) { yolo2_set_error("image_prep: memset failed"); return YOLO2_E_LAUNCH; }
-        dim3 grid(B >= 64 ? 8 : B >= 8 ? 32 : 128, B);
-        image_sums_kernel<<<grid, 256, 0, st>>>(img, ws, (long)HW * 3);
+        parts = Y2_IMG_PARTS;
+        image_sums_kernel<<<dim3(parts, B), 256, 0, st>>>(img, ws, (long)HW * 3);
     }
-    Y2_DISPATCH_DTYPE(dtype, image_apply_kernel<T><<<ew_grid((long)B * HW), 256, 0, st>>>(img, (T *)out, ws, B, HW, mode));
+    int gx = (int)(((long)HW + 1023) / 1024);        // ~4 pixels per thread
+    if (gx > 256) gx = 256;
+    if ((long)gx * B > 8192) gx = 8192 / B > 0 ? 8192 / B : 1;
+    Y2_DISPATCH_DTYPE(dtype, image_apply_kernel<T><<<dim3(gx, B), 256, 0, st>>>(img, (T *)out, ws, (long)HW, mode, parts));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -1584,7 +1615,7 @@ extern "C" int yolo2_debug_noop(void *stream) {
 // ---- workspace sizes (bytes) of the entries that take a caller-owned scratch buffer: the single source of truth for callers
 extern "C" size_t yolo2_bn_workspace_bytes(int C) { return (size_t)1025 * (size_t)(C > 0 ? C : 0) * sizeof(double); }
 extern "C" size_t yolo2_bias_grad_workspace_bytes(int ld) { return (size_t)512 * (size_t)(ld > 0 ? ld : 0) * sizeof(double); }
-extern "C" size_t yolo2_image_prep_workspace_bytes(int B) { return (size_t)2 * (size_t)(B > 0 ? B : 0) * sizeof(double); }
+extern "C" size_t yolo2_image_prep_workspace_bytes(int B) { return (size_t)2 * Y2_IMG_PARTS * (size_t)(B > 0 ? B : 0) * sizeof(double); }
 extern "C" size_t yolo2_clip_workspace_bytes(int nseg) { return (size_t)(nseg > 0 ? nseg : 0) * sizeof(double); }
 extern "C" size_t yolo2_augment_workspace_bytes(int B) { return (size_t)3 * (size_t)(B > 0 ? B : 0) * sizeof(double); }
 extern "C" size_t yolo2_nms_workspace_bytes(int B, int N, int C) { return (size_t)(B > 0 ? B : 0) * (size_t)(N > 0 ? N : 0) * (size_t)(C > 0 ? C : 0) * sizeof(int); }

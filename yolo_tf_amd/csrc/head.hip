@@ -126,11 +126,11 @@ static int lanes_per_cell(int A) {
     return l;
 }
 
-extern "C" int yolo2_loss(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
-                          const float *coords, const float *off_min, const float *off_max, const float *areas,
-                          const float *hparam, float *objectives, void *dlogits, float *ws, int B, int cell_h,
-                          int cell_w, int A, int C, int dtype, void *stream) {
-    Y2_CHECK_ARG(logits && anchors && mask && prob && coords && off_min && off_max && areas && hparam && objectives && ws);
+static int loss_impl(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
+                     const float *coords, const float *off_min, const float *off_max, const float *areas,
+                     const float *hparam, float *objectives, void *dlogits, float *ws, int B, int cell_h,
+                     int cell_w, int A, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(logits && anchors && mask && prob && coords && off_min && off_max && areas && hparam && ws);
     Y2_CHECK_ARG(B > 0 && cell_h > 0 && cell_w > 0 && A > 0 && A <= 64 && C > 0 && ld >= A * (5 + C));
     hipStream_t st = (hipStream_t)stream;
     const int LPC = lanes_per_cell(A);
@@ -141,7 +141,29 @@ extern "C" int yolo2_loss(const void *logits, int ld, const float *anchors, cons
     hp[0] = hparam[0]; hp[1] = hparam[1]; hp[2] = hparam[2]; hp[3] = hparam[3];
     Y2_DISPATCH_DTYPE(dtype, loss_kernel<T><<<nblocks, 256, 0, st>>>((const T *)logits, ld, anchors, mask, prob, coords, off_min, off_max, areas,
                                                                      hp[0], hp[1], hp[2], hp[3], (T *)dlogits, ws, B, cell_h, cell_w, A, C, LPC));
-    loss_finalize_kernel<<<1, 256, 0, st>>>(ws, nblocks, (float)((long)B * cell_h * cell_w * A), objectives);
+    if (objectives) loss_finalize_kernel<<<1, 256, 0, st>>>(ws, nblocks, (float)((long)B * cell_h * cell_w * A), objectives);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_loss(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
+                          const float *coords, const float *off_min, const float *off_max, const float *areas,
+                          const float *hparam, float *objectives, void *dlogits, float *ws, int B, int cell_h,
+                          int cell_w, int A, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(objectives);
+    return loss_impl(logits, ld, anchors, mask, prob, coords, off_min, off_max, areas, hparam, objectives, dlogits, ws, B, cell_h, cell_w, A, C, dtype, stream);
+}
+// The training step needs only dlogits; the four objective values are read a few times a minute (summaries).  yolo2_loss_partials runs the
+// loss kernel alone (per-workgroup partial sums stay in ws), yolo2_loss_objectives reduces them when somebody asks -- one launch less
+// on the step's critical path.  Together they equal yolo2_loss.
+extern "C" int yolo2_loss_partials(const void *logits, int ld, const float *anchors, const float *mask, const float *prob,
+                                   const float *coords, const float *off_min, const float *off_max, const float *areas,
+                                   const float *hparam, void *dlogits, float *ws, int B, int cell_h, int cell_w, int A, int C, int dtype, void *stream) {
+    return loss_impl(logits, ld, anchors, mask, prob, coords, off_min, off_max, areas, hparam, nullptr, dlogits, ws, B, cell_h, cell_w, A, C, dtype, stream);
+}
+extern "C" int yolo2_loss_objectives(const float *ws, float *objectives, int B, int cell_h, int cell_w, int A, void *stream) {
+    Y2_CHECK_ARG(ws && objectives && B > 0 && cell_h > 0 && cell_w > 0 && A > 0 && A <= 64);
+    const int nblocks = cdiv((long)B * cell_h * cell_w * lanes_per_cell(A), 256);
+    loss_finalize_kernel<<<1, 256, 0, (hipStream_t)stream>>>(ws, nblocks, (float)((long)B * cell_h * cell_w * A), objectives);
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }

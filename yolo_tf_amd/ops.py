@@ -228,6 +228,18 @@ def loss(logits, ld, anchors, labels, hparam, objectives, dlogits, ws, B, ch, cw
          ptr(objectives), ptr(dlogits), ptr(ws), B, ch, cw, A, C, dtype_code(logits.dtype), _stream())
 
 
+def loss_partials(logits, ld, anchors, labels, hparam, dlogits, ws, B, ch, cw, A, C):
+    """The loss kernel alone: dlogits + per-workgroup partial sums in ``ws``; ``loss_objectives`` reduces them on demand."""
+    hp = (ctypes.c_float * 4)(*[float(v) for v in hparam])
+    mask, prob, coords, omin, omax, areas = labels
+    call('yolo2_loss_partials', ptr(logits), ld, ptr(anchors), ptr(mask), ptr(prob), ptr(coords), ptr(omin), ptr(omax), ptr(areas), hp,
+         ptr(dlogits), ptr(ws), B, ch, cw, A, C, dtype_code(logits.dtype), _stream())
+
+
+def loss_objectives(ws, objectives, B, ch, cw, A):
+    call('yolo2_loss_objectives', ptr(ws), ptr(objectives), B, ch, cw, A, _stream())
+
+
 def loss_ws_floats(B, cells, A):
     return workspace_bytes('loss', B, cells, A) // 4
 

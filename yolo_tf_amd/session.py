@@ -105,8 +105,9 @@ class TrainSession(object):
         if self.v1:
             ops.yolo1_loss(logits, ld, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws, self.B, m.cell_height, m.cell_width, self.A, self.C)
         else:
-            ops.loss(logits, ld, self.anchors, self.labels, self.hparam, self.objectives_dev, dlogits, self.loss_ws,
-                     self.B, m.cell_height, m.cell_width, self.A, self.C)
+            # (the four objective values are reduced from the partial sums when fetch() asks for them)
+            ops.loss_partials(logits, ld, self.anchors, self.labels, self.hparam, dlogits, self.loss_ws, self.B, m.cell_height, m.cell_width, self.A, self.C)
+            self._objectives_pending = (m.cell_height, m.cell_width)
         if self.reducer is not None:
             self.reducer.begin()
             e.backward(on_layer_done=lambda op, ev: self.reducer.ready_upto(self._layer_end[op['name']], ev))
@@ -153,6 +154,9 @@ class TrainSession(object):
     def fetch(self):
         """Synchronises and returns {'total_loss', 'iou_best', 'iou_normal', 'coords', 'prob'} of the last step
         (the five scalars the reference summarises, config.ini:63)."""
+        if getattr(self, '_objectives_pending', None):
+            ops.loss_objectives(self.loss_ws, self.objectives_dev, self.B, self._objectives_pending[0], self._objectives_pending[1], self.A)
+            self._objectives_pending = None
         vals = self.objectives_dev.cpu().numpy().astype(np.float64)
         out = {k: float(v) for k, v in zip(OBJECTIVE_KEYS, vals)}
         out['regularization'] = float(self.engine.reg_loss.item())        # slim.l2_regularizer terms (YOLO v1 fully connected layers; 0 for yolo2)

@@ -11,7 +11,7 @@ def _prep(image, mode):
     h, w, c = image.shape
     assert c == 3
     out = torch.zeros(h * w * 8, dtype=torch.float32, device='cuda')
-    ws = torch.zeros(2, dtype=torch.float64, device='cuda')
+    ws = torch.zeros(ops.workspace_bytes('image_prep', 1) // 8, dtype=torch.float64, device='cuda')
     ops.image_prep(torch.from_numpy(image).cuda(), out, ws, 1, h * w, mode)
     return out.reshape(h, w, 8)[..., :3].cpu().numpy()
 
