@@ -204,6 +204,27 @@ int yolo2_bn_leaky_pool_bwd_reduce_part(const void *dP, int lddp, const unsigned
                                         const float *var, const float *gamma, const float *beta, double *ws, int *rows,
                                         int rows_limit, int B, int H, int W, int C, float eps, float alpha, int dtype, void *stream);
 
+/* ---- The image layer fused with its consumers: conv0 (3 -> 32 filters, 3x3; model/yolo2/inference.py:72-74 `net = conv2d(net, 32)` followed
+ * by `max_pool2d`) is 0.9 % of the arithmetic but its raw output is the largest tensor of the network (5.5 M pixels x 32 channels per
+ * image).  These entries never store it: each one re-computes the output patch it needs from the image (P: [B,H,W,8], 3 real channels;
+ * F: the forward filter operand of yolo2_filter_prep, [32][72]) and applies its elementwise work to the accumulators.  Results equal
+ *   yolo2_conv2d_bn + yolo2_bn_finalize                      (yolo2_first_layer_stats + yolo2_bn_finalize)
+ *   yolo2_bn_leaky_pool on the stored output                 (yolo2_first_layer_bn_leaky_pool)
+ *   yolo2_bn_leaky_pool_bwd_reduce / _bwd_apply               (yolo2_first_layer_pool_bwd_reduce + yolo2_bn_part_to_grads / ..._bwd_apply)
+ * bit for bit up to f32 summation order: the recomputed output is rounded to dtype exactly where the unfused path stores it.
+ * H and W even; bn_part: f32 [2][YOLO2_BN_PART_ROWS][32], zero on entry. */
+int yolo2_first_layer_stats(const void *P, const void *F, int B, int H, int W, const float *shift, float *bn_part, int dtype, void *stream);
+int yolo2_first_layer_bn_leaky_pool(const void *P, const void *F, const float *mean, const float *var, const float *gamma,
+                                    const float *beta, void *Pout, unsigned char *idx, int B, int H, int W, int ldp, float eps,
+                                    float alpha, int dtype, void *stream);
+int yolo2_first_layer_pool_bwd_reduce(const void *P, const void *F, const void *dP, int lddp, const unsigned char *idx,
+                                      const float *mean, const float *var, const float *gamma, const float *beta, float *bn_part,
+                                      int B, int H, int W, float eps, float alpha, int dtype, void *stream);
+int yolo2_first_layer_pool_bwd_apply(const void *P, const void *F, const void *dP, int lddp, const unsigned char *idx,
+                                     const float *mean, const float *var, const float *gamma, const float *beta,
+                                     const float *dgamma, const float *dbeta, void *dY, int B, int H, int W, float eps, float alpha,
+                                     int dtype, void *stream);
+
 /* ---- batch norm + leaky ReLU: closure model/yolo2/inference.py:62-66 + model/yolo/function.py:21-24
  * Y is the raw convolution output [M = B*H*W][C] (pixel stride C). */
 /* batch mean and biased variance over M rows (tf.nn.moments); ws: >= 1025*C doubles of scratch

@@ -23,7 +23,7 @@ def short(n):
     return n[:84]
 
 def last_step(rows):
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    adam = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_filter_prep_kernel' in r[0])]
     return rows[adam[-2] + 1: adam[-1] + 1]
 
 def main():

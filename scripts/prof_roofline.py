@@ -27,7 +27,7 @@ def dominant(name):
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = load(path)
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    adam = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_filter_prep_kernel' in r[0])]
     sel = rows[adam[-steps - 1] + 1: adam[-1] + 1]
     dom = [(n, e - s) for n, s, e in sel if dominant(n)]
     tot = sum(d for _, d in dom)
@@ -54,7 +54,7 @@ def main():
                         e = rows.setdefault(int(r['Dispatch_Id']), [r['Kernel_Name'], 0.0])
                         e[1] += float(r['Counter_Value'])
             rows = [rows[k] for k in sorted(rows)]
-            ad = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+            ad = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_filter_prep_kernel' in r[0])]
             return rows[ad[-2] + 1: ad[-1] + 1]
         fe, wr = counter(sys.argv[3], 'FETCH_SIZE'), counter(sys.argv[4], 'WRITE_SIZE')
         f = [v * 1024 * 2 for n, v in fe if dominant(n)]

@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from prof_summary import load, short
 rows = load(sys.argv[1])
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+adam = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_filter_prep_kernel' in r[0])]
 sel = rows[adam[-2] + 1: adam[-1] + 1]
 t0 = sel[0][1]
 prev_end = t0

@@ -24,7 +24,7 @@ def short(n):
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     rows = load(path)
-    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    adam = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_filter_prep_kernel' in r[0])]
     lo, hi = adam[-steps - 1] + 1, adam[-1] + 1          # the last `steps` training steps
     sel = rows[lo:hi]
     wall = (sel[-1][2] - sel[0][1]) / 1e6 / steps

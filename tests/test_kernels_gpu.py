@@ -613,6 +613,78 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
     assert_close(host(mv), R.bn_ema(np.ones(C, np.float32), var_r), 1e-5, 'ema var')
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 32, 32), (3, 18, 40), (2, 416, 416)])
+def test_first_layer_fused_with_bn_leaky_pool(ops, shape, mode):
+    """yolo2_first_layer_* (the image layer's output recomputed inside its consumers, never stored) against the stored-output path --
+    yolo2_conv2d_bn + bn_finalize, bn_leaky_pool, bn_leaky_pool_bwd_reduce / _bwd_apply -- which the oracle tests above pin: pooled
+    activation and arg-max bit for bit, statistics / dgamma / dbeta up to f32 summation order, dY to the last bit or two;
+    plus the oracle directly on the small shapes."""
+    B, H, W = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(H + W)
+    img = rng.randn(B, H, W, 3).astype(np.float32)
+    w = (rng.randn(3, 3, 3, 32) * 0.3).astype(np.float32)
+    if mode == 'bf16':
+        img = bf16_round(img)
+    x = dev(pad_channels(img, 8), tdtype)
+    F = torch.zeros(32 * 9 * 8, dtype=tdtype, device='cuda')
+    ops.filter_prep(dev(w), F, None, 3, 3, 8, 32, 32, tdtype)
+    gamma, beta = dev((rng.rand(32) + 0.5).astype(np.float32)), dev((rng.randn(32) * 0.2).astype(np.float32))
+    shift = dev((rng.randn(32) * 0.1).astype(np.float32))
+    M, MP = B * H * W, B * (H // 2) * (W // 2)
+    ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
+    red = torch.zeros(ops.workspace_bytes('bn', 32) // 8, dtype=torch.float64, device='cuda')
+    # ---- stored-output path
+    y = torch.zeros(M * 32, dtype=tdtype, device='cuda')
+    part = torch.zeros(2 * 256 * 32, dtype=torch.float32, device='cuda')
+    mean0, var0 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    ops.conv2d_bn(x, F, y, ws, B, H, W, 8, 8, 32, 32, 3, shift, part)
+    assert ops.last_conv_plan()['BM'] == -1          # the direct image-layer kernel
+    ops.bn_finalize(part, shift, M, 32, mean0, var0, None, None, 0.999)
+    P0 = torch.zeros(MP * 32, dtype=tdtype, device='cuda')
+    idx0 = torch.full((MP * 32,), 9, dtype=torch.uint8, device='cuda')
+    ops.bn_leaky_pool(y, mean0, var0, gamma, beta, P0, idx0, B, H, W, 32, 32, 1e-5, 0.1)
+    dp = rng.randn(B, H // 2, W // 2, 32).astype(np.float32)
+    dpd = dev(bf16_round(dp) if mode == 'bf16' else dp, tdtype)
+    dg0, db0 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    ops.bn_leaky_pool_bwd_reduce(dpd, 32, idx0, y, mean0, var0, gamma, beta, dg0, db0, red, B, H, W, 32, 1e-5, 0.1)
+    dy0 = torch.zeros(M * 32, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply(dpd, 32, idx0, y, mean0, var0, gamma, beta, dg0, db0, dy0, B, H, W, 32, 1e-5, 0.1)
+    # ---- fused path
+    mean1, var1 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    ops.first_layer_stats(x, F, B, H, W, shift, part)
+    ops.bn_finalize(part, shift, M, 32, mean1, var1, None, None, 0.999)
+    P1 = torch.zeros(MP * 32, dtype=tdtype, device='cuda')
+    idx1 = torch.full((MP * 32,), 9, dtype=torch.uint8, device='cuda')
+    ops.first_layer_bn_leaky_pool(x, F, mean0, var0, gamma, beta, P1, idx1, B, H, W, 32, 1e-5, 0.1)       # (same moments as the stored path: bit-exact comparison)
+    dg1, db1 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    ops.first_layer_pool_bwd_reduce(x, F, dpd, 32, idx0, mean0, var0, gamma, beta, part, B, H, W, 1e-5, 0.1)
+    ops.bn_part_to_grads(part, 32, dg1, db1)
+    dy1 = torch.full((M * 32,), 7.0, dtype=tdtype, device='cuda')
+    ops.first_layer_pool_bwd_apply(x, F, dpd, 32, idx0, mean0, var0, gamma, beta, dg0, db0, dy1, B, H, W, 1e-5, 0.1)
+    P2 = torch.zeros(MP * 32, dtype=tdtype, device='cuda')
+    ops.first_layer_bn_leaky_pool(x, F, mean0, var0, gamma, beta, P2, None, B, H, W, 32, 1e-5, 0.1)         # inference form: no arg-max output
+    torch.cuda.synchronize()
+    assert float(part.abs().max()) == 0.0
+    assert_close(host(mean1), host(mean0), 2e-6, 'mean')
+    assert_close(host(var1), host(var0), 2e-5, 'var')
+    assert torch.equal(P1, P0) and torch.equal(idx1, idx0) and torch.equal(P2, P0)
+    assert_close(host(dg1), host(dg0), 2e-5, 'dgamma')
+    assert_close(host(db1), host(db0), 2e-5, 'dbeta')
+    # (dY goes through a few f32 multiply-adds that the two kernels' compilations may contract differently: last-bit agreement)
+    assert_close(host(dy1), host(dy0), 2e-6 if mode == 'f32' else 8e-3, 'dY')
+    assert float((dy1.float() - dy0.float()).abs().mean()) <= (1e-7 if mode == 'f32' else 2e-4) * float(dy0.float().abs().mean() + 1e-30)
+    if M <= 20000:        # the oracle directly
+        yq = R.conv2d(img, bf16_round(w) if mode == 'bf16' else w)
+        if mode == 'bf16':
+            yq = bf16_round(yq)
+        a = R.leaky_relu(R.bn_apply(yq, host(mean0), host(var0), host(gamma), host(beta)))
+        if mode == 'bf16':
+            a = bf16_round(a)
+        assert_close(host(P1).reshape(B, H // 2, W // 2, 32), R.max_pool(a, 2), F32_RTOL if mode == 'f32' else BF16_RTOL, 'pooled activation vs oracle')
+
+
 def _host_partials(vals0, vals1, rows, C, plane_rows, rng, poison):
     """[2][plane_rows][C] f32 partial rows: the M samples of each channel dealt to ``rows`` groups at random (what a producer's tiles
     leave behind); rows >= ``rows`` hold NaN when ``poison`` (a consumer must not read them)."""

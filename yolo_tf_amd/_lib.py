@@ -35,6 +35,10 @@ SIGNATURES = {
     'yolo2_filter_prep': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_filter_prep_batch': [_p, _i, _i, _i, _p],
     'yolo2_adam_filter_prep': [_p, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _f, _f, _f, _i, _p],
+    'yolo2_first_layer_stats': [_p, _p, _i, _i, _i, _p, _p, _i, _p],
+    'yolo2_first_layer_bn_leaky_pool': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _i, _p],
+    'yolo2_first_layer_pool_bwd_reduce': [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
+    'yolo2_first_layer_pool_bwd_apply': [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
     'yolo2_conv2d_bn': [_p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
     'yolo2_bn_finalize': [_p, _p, _l, _i, _p, _p, _p, _p, ctypes.c_double, _p],
     'yolo2_bn_leaky_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _l, _i, _i, _f, _f, _p, _l, _i, _p],

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict
             const int px = (r & 3) + 8 * (r >> 2) + 4 * half;
             if (w0 + px < W) {
                 const T o = (T)acc[r];
-                out[(long)px * 32] = o;
+                if (Y) out[(long)px * 32] = o;               // Y == NULL: statistics only (the output is recomputed by its consumers: fused kernels below)
                 const float d = (float)o - sh;
                 s1 += d;
                 s2 += d * d;
@@ -145,6 +145,170 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict
             const int slot = (blockIdx.x * 4 + wave) & (Y2_BN_PART_ROWS - 1);
             unsafeAtomicAdd(bn_part + slot * 32 + n, s1);
             unsafeAtomicAdd(bn_part + (Y2_BN_PART_ROWS + slot) * 32 + n, s2);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Image layer fused with its consumers (round 3): the raw output of conv0 is 5.5 M pixels x 32 channels per image -- 177 MB at batch 16,
+// 2.8 GB at batch 256 -- written once and read back three times (BN + leaky + pool forward, BN-backward reduce, BN-backward apply) while
+// its input is 1/4 of that (16 B per pixel) and its arithmetic 0.9 % of the network.  These kernels never store it: every consumer
+// RE-COMPUTES its 2 x 32-pixel patch from a 4 x 34-pixel input halo (ten MFMAs) and applies its own elementwise work to the accumulators:
+//   MODE 0  forward:  y -> BN -> leaky -> 2x2 max pool -> P (+ first-max index), as yolo2_bn_leaky_pool on a stored y
+//   MODE 1  backward: sum(g * xhat), sum(g) per channel into the partial rows (g = dP * leaky'(z) at the arg-max), as ..._pool_bwd_reduce
+//   MODE 2  backward: dY (full resolution, for the filter gradient), as ..._pool_bwd_apply
+// The recomputed y is rounded to T exactly where the unfused path stored it, so every result equals the unfused path's (same MFMA order,
+// same rounding points); batch statistics come from a statistics-only pass of conv_first_fwd_kernel (Y = NULL).
+// A wave owns one pooled row segment: output rows 2*h2, 2*h2+1, pixels w0 .. w0+31.  The 32x32 accumulator layout puts filter n in lane
+// n (both halves) and pixel (r&3) + 8*(r>>2) + 4*half in register r: a pooling window is registers {r0, r0+1} of the two rows' tiles in
+// ONE lane, so the pool, its arg-max and the routing of dP need no cross-lane traffic at all.
+// ---------------------------------------------------------------------------------------------------
+struct Y2FirstBn { const float *mean, *var, *gamma, *beta, *dgamma, *dbeta; float eps, alpha; };
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void conv_first_pool_kernel(const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ F, T *__restrict__ Out,
+                                                              unsigned char *__restrict__ idx, const T *__restrict__ dP, int lddp, float *__restrict__ part,
+                                                              int B, int H, int W, int ldo, int units, const Y2FirstBn bn) {
+    constexpr int PXB = First<T>::PXB, HROWB = First<T>::HROWB, SLOT = 4 * HROWB;
+    constexpr int LOADS = 4 * First<T>::HPIECES;
+    constexpr int KS = sizeof(T) == 2 ? 5 : 36;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * 2 * SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *my = smem + wave * 2 * SLOT;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), 0, x_bytes, 0x00020000);
+    const int SW = (W + 31) / 32, OH = H / 2, OW = W / 2;
+
+    typename std::conditional<sizeof(T) == 2, bf16x8, float>::type bf[KS];
+    const int n = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = s * 16 + half * 8 + e;
+                bf[s][e] = k < 72 ? F[n * 72 + k] : (bf16)0.f;
+            }
+        } else {
+            bf[s] = F[n * 72 + s * 2 + half];
+        }
+    }
+    // this lane's channel constants (one filter per lane)
+    const float mu = bn.mean[n], inv = 1.0f / sqrtf(bn.var[n] + bn.eps), ga = bn.gamma[n], bt = bn.beta[n];
+    const float sc = inv * ga;
+    const float invM = 1.0f / (float)((long)B * H * W);
+    const float dgm = MODE == 2 ? bn.dgamma[n] * invM : 0.f, dbm = MODE == 2 ? bn.dbeta[n] * invM : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+
+    const int stride = gridDim.x * 4;
+    int u = blockIdx.x * 4 + wave;
+    if (u >= units) return;
+    auto decode = [&](int uu, int &b, int &h2, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h2 = t % OH; b = t / OH; };
+    auto stage = [&](unsigned char *dst, int b, int h2, int w0) {      // halo rows 2*h2-1 .. 2*h2+2, pixels w0-1 .. w0+32
+        constexpr int HP = First<T>::HPIECES;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int hh = 2 * h2 - 1 + r;
+#pragma unroll
+            for (int p = 0; p < HP; ++p) {
+                const int chunk = p * 64 + lane;
+                const int px = chunk / HP;
+                const int ww = w0 - 1 + px;
+                const bool ok = px < 34 && (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
+                const unsigned voff = ok ? (unsigned)((((long)b * H + hh) * W + ww) * PXB + (chunk % HP) * 16) : Y2_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(dst + r * HROWB + p * 1024), 16, voff, 0, 0, 0);
+            }
+        }
+    };
+    int b, h2, w0;
+    decode(u, b, h2, w0);
+    stage(my, b, h2, w0);
+    int st = 0;
+    for (; u < units; u += stride) {
+        const int un = u + stride;
+        int nb = 0, nh2 = 0, nw0 = 0;
+        if (un < units) {
+            decode(un, nb, nh2, nw0);
+            stage(my + (st ^ 1) * SLOT, nb, nh2, nw0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char *hs = my + st * SLOT;
+        f32x16 acc[2];
+        const int i = lane & 31;
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rho][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if constexpr (sizeof(T) == 2) {
+                    int tap = 2 * s + half;
+                    if (tap > 8) tap = 8;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8 *>(hs + (rho + tap / 3) * HROWB + (i + tap % 3) * PXB);
+                    acc[rho] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bf[s], acc[rho], 0, 0, 0);
+                } else {
+                    const int k = 2 * s + half, tap = k >> 3, c = k & 7;
+                    const float a = *reinterpret_cast<const float *>(hs + (rho + tap / 3) * HROWB + (i + tap % 3) * PXB + c * 4);
+                    acc[rho] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bf[s], acc[rho], 0, 0, 0);
+                }
+            }
+        }
+        // y as the unfused path stores it (rounded to T), window by window: registers r0, r0+1 of both rows = the 2x2 window of pooled
+        // pixel p = 4q + 2*half + j of this segment
+        const long prow = ((long)b * OH + h2) * OW + (w0 >> 1);       // first pooled pixel of the segment
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r0 = 4 * q + 2 * j, p = 4 * q + 2 * half + j;
+                if (w0 + 2 * p >= W) continue;
+                float y[4] = {(float)(T)acc[0][r0], (float)(T)acc[0][r0 + 1], (float)(T)acc[1][r0], (float)(T)acc[1][r0 + 1]};
+                if (MODE == 0) {
+                    float a[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float z = (y[k] - mu) * sc + bt;
+                        a[k] = (float)(T)fmaxf(z, bn.alpha * z);
+                    }
+                    const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+                    const int arg = a[0] == m ? 0 : a[1] == m ? 1 : a[2] == m ? 2 : 3;
+                    Out[(prow + p) * ldo + n] = (T)m;
+                    if (idx) idx[(prow + p) * 32 + n] = (unsigned char)arg;
+                } else {
+                    const float d = (float)dP[(prow + p) * lddp + n];
+                    const int k = (int)idx[(prow + p) * 32 + n];
+                    if (MODE == 1) {
+                        const float yk = k == 0 ? y[0] : k == 1 ? y[1] : k == 2 ? y[2] : y[3];
+                        const float xh = (yk - mu) * inv;
+                        const float z = (yk - mu) * (inv * ga) + bt;
+                        const float g = z >= 0.f ? d : bn.alpha * d;
+                        s0 += g * xh;
+                        s1 += g;
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const float da = k == kk ? d : 0.f;
+                            const float xh = (y[kk] - mu) * inv;
+                            const float z = (y[kk] - mu) * (inv * ga) + bt;
+                            const float g = z >= 0.f ? da : bn.alpha * da;
+                            const long pix = ((long)b * H + 2 * h2 + (kk >> 1)) * W + w0 + 2 * p + (kk & 1);
+                            Out[pix * 32 + n] = (T)((ga * inv) * (g - dbm - xh * dgm));
+                        }
+                    }
+                }
+            }
+        b = nb; h2 = nh2; w0 = nw0;
+        st ^= 1;
+    }
+    if (MODE == 1) {
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (lane < 32) {
+            const int slot = (blockIdx.x * 4 + wave) & (Y2_BN_PART_ROWS - 1);
+            unsafeAtomicAdd(part + slot * 32 + n, s0);
+            unsafeAtomicAdd(part + (Y2_BN_PART_ROWS + slot) * 32 + n, s1);
         }
     }
 }
@@ -305,4 +469,48 @@ int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     else
         conv_first_wgrad_kernel<float><<<grid, 256, 0, st>>>((const float *)X, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)dY, (unsigned)((size_t)B * H * W * 32 * 4), dW, B, H, W, Cin, units);
     return 0;
+}
+
+// ---- fused image layer (conv_first_pool_kernel): host side.  P: image [B,H,W,8] (3 real channels), F: forward filter operand [32][72]
+static bool first_pool_ok(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0; }
+template <int MODE>
+static int first_pool_launch(const void *P, const void *F, void *Out, unsigned char *idx, const void *dP, int lddp, float *part, int B, int H, int W, int ldo,
+                             const Y2FirstBn &bn, int dtype, hipStream_t st) {
+    const int units = B * (H / 2) * ((W + 31) / 32);
+    const int grid = units / 4 + 1 < 2048 ? units / 4 + 1 : 2048;
+    if (dtype == YOLO2_BF16)
+        conv_first_pool_kernel<bf16, MODE><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)Out, idx, (const bf16 *)dP, lddp,
+                                                                 part, B, H, W, ldo, units, bn);
+    else if (dtype == YOLO2_F32)
+        conv_first_pool_kernel<float, MODE><<<grid, 256, 0, st>>>((const float *)P, (unsigned)((size_t)B * H * W * 8 * 4), (const float *)F, (float *)Out, idx, (const float *)dP, lddp,
+                                                                  part, B, H, W, ldo, units, bn);
+    else { yolo2_set_error("first layer: bad dtype %d", dtype); return YOLO2_E_ARG; }
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_first_layer_stats(const void *P, const void *F, int B, int H, int W, const float *shift, float *bn_part, int dtype, void *stream) {
+    Y2_CHECK_ARG(P && F && shift && bn_part && B > 0 && H > 0 && W > 0 && (dtype == YOLO2_F32 || dtype == YOLO2_BF16));
+    y2_first_layer_fwd(P, F, nullptr, B, H, W, dtype, (hipStream_t)stream, shift, bn_part);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+extern "C" int yolo2_first_layer_bn_leaky_pool(const void *P, const void *F, const float *mean, const float *var, const float *gamma, const float *beta, void *Pout,
+                                               unsigned char *idx, int B, int H, int W, int ldp, float eps, float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(P && F && mean && var && gamma && beta && Pout && ldp >= 32 && first_pool_ok(B, H, W));
+    const Y2FirstBn bn{mean, var, gamma, beta, nullptr, nullptr, eps, alpha};
+    return first_pool_launch<0>(P, F, Pout, idx, nullptr, 0, nullptr, B, H, W, ldp, bn, dtype, (hipStream_t)stream);
+}
+extern "C" int yolo2_first_layer_pool_bwd_reduce(const void *P, const void *F, const void *dP, int lddp, const unsigned char *idx, const float *mean, const float *var,
+                                                 const float *gamma, const float *beta, float *bn_part, int B, int H, int W, float eps, float alpha, int dtype,
+                                                 void *stream) {
+    Y2_CHECK_ARG(P && F && dP && idx && mean && var && gamma && beta && bn_part && lddp >= 32 && first_pool_ok(B, H, W));
+    const Y2FirstBn bn{mean, var, gamma, beta, nullptr, nullptr, eps, alpha};
+    return first_pool_launch<1>(P, F, nullptr, const_cast<unsigned char *>(idx), dP, lddp, bn_part, B, H, W, 0, bn, dtype, (hipStream_t)stream);
+}
+extern "C" int yolo2_first_layer_pool_bwd_apply(const void *P, const void *F, const void *dP, int lddp, const unsigned char *idx, const float *mean, const float *var,
+                                                const float *gamma, const float *beta, const float *dgamma, const float *dbeta, void *dY, int B, int H, int W,
+                                                float eps, float alpha, int dtype, void *stream) {
+    Y2_CHECK_ARG(P && F && dP && idx && mean && var && gamma && beta && dgamma && dbeta && dY && lddp >= 32 && first_pool_ok(B, H, W));
+    const Y2FirstBn bn{mean, var, gamma, beta, dgamma, dbeta, eps, alpha};
+    return first_pool_launch<2>(P, F, dY, const_cast<unsigned char *>(idx), dP, lddp, nullptr, B, H, W, 32, bn, dtype, (hipStream_t)stream);
 }

@@ -202,6 +202,9 @@ class Engine(object):
         self.parts = _PartPool(3, 2 * 256 * max(max_c, 8), dev)
         self.bn_part = self.parts.bufs[0]                       # (kept for callers that drive the two-launch form directly)
         self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0'
+        # image layer recomputed inside its consumers instead of stored: 'infer' (default: detect only -- batch 256: 12.5 -> 11.3 ms),
+        # '1' (training too: measured neutral, the recomputing backward kernels are VALU-bound -- profiles/r03_first_layer_fused.md), '0' never
+        self.fuse_first = os.environ.get('YOLO2_FUSE_FIRST', 'infer')
         self._bz_pending = {}                                    # producer layer -> (buffer, rows): BN-backward sums waiting for their apply pass
         self._fin_rows_limit = {}
         # scratch sizes come from the library's own queries (include/yolo2_hip.h yolo2_*_workspace_bytes)
@@ -450,6 +453,23 @@ class Engine(object):
                 if op['bn'] and 'fold_bias' in st:
                     ob, ldo = self.act[out]
                     ops.conv2d_bias_leaky(xb, st['Ffwd'], st['fold_bias'], ob, self.conv_ws, B, x.h, x.w, pad8(x.c), ldx, op['cout'], ldo, op['ksize'], LEAKY_ALPHA)
+                elif op['bn'] and self._first_fused(op):
+                    # image layer: its raw output (the largest tensor of the network) is never stored; the statistics pass and the
+                    # BN + leaky + pool pass each recompute it from the image (csrc/conv_first.hip: conv_first_pool_kernel)
+                    gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
+                    mmean, mvar = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
+                    pool = self.fused_pool[out]
+                    pb, ldp = self.act[pool['out']]
+                    if self.training:
+                        part = self.parts.acquire(2 * 256 * 32)
+                        ops.first_layer_stats(xb, st['Ffwd'], B, x.h, x.w, mmean, self.parts.bufs[part])
+                        ops.bn_finalize(self.parts.bufs[part], mmean, M, 32, st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                        self.parts.consumed(part, cleared=True)
+                        mean, var = st['mean'], st['var']
+                    else:
+                        mean, var = mmean, mvar
+                    ops.first_layer_bn_leaky_pool(xb, st['Ffwd'], mean, var, gamma, beta, pb, st.get('pool_idx') if self.training else None,
+                                                  B, x.h, x.w, ldp, BN_EPS, LEAKY_ALPHA)
                 elif op['bn']:
                     yb, ldy = self.act[op['y']]
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
@@ -575,7 +595,15 @@ class Engine(object):
                     # below sums them in its prologue (one launch instead of reduce-finalise + apply)
                     pfin = None
                     limit = self._fin_limit(cout) if self.fold_finalize else 0
-                    if pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
+                    first = self._first_fused(op)
+                    if first:                 # image layer: y is recomputed from the image inside both backward kernels
+                        dpb, lddp = self.gact[pool['out']]
+                        part = self.parts.acquire(2 * 256 * 32)
+                        ops.first_layer_pool_bwd_reduce(xb, st['Ffwd'], dpb, lddp, st['pool_idx'], st['mean'], st['var'], gamma, beta, self.parts.bufs[part],
+                                                        B, x.h, x.w, BN_EPS, LEAKY_ALPHA)
+                        ops.bn_part_to_grads(self.parts.bufs[part], 32, dgam, dbet)
+                        self.parts.consumed(part, cleared=True)
+                    elif pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
                         dpb, lddp = self.gact[pool['out']]
                         if limit >= 128:
                             rows = ops.bn_leaky_pool_bwd_reduce_part(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, self.ws, limit,
@@ -597,7 +625,10 @@ class Engine(object):
                     dy = self.dy_ring[slot]
                     if self.dy_free[slot] is not None:
                         main.wait_event(self.dy_free[slot])       # the filter gradient that last read this buffer is done
-                    if pfin is not None:
+                    if first:
+                        ops.first_layer_pool_bwd_apply(xb, st['Ffwd'], dpb, lddp, st['pool_idx'], st['mean'], st['var'], gamma, beta, dgam, dbet, dy,
+                                                       B, x.h, x.w, BN_EPS, LEAKY_ALPHA)
+                    elif pfin is not None:
                         own = pfin[3] if len(pfin) > 3 else -1
                         zbuf, zn = self.parts.take_to_zero(own)
                         if pool is not None:
@@ -692,6 +723,16 @@ class Engine(object):
         self._phase = 'fwd'
         if side is not None:
             main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
+
+    def _first_fused(self, op):
+        """The image layer (3 channels in an 8-wide pixel, 32 filters, 3x3, batch-normalised, followed only by a 2x2 pool) takes the
+        recompute-instead-of-store kernels; YOLO2_FUSE_FIRST=0 keeps the stored-output path (A/B, and tests that read the raw output)."""
+        if self.fuse_first == '0' or (self.training and self.fuse_first != '1'):
+            return False
+        x, out = op['x'], op['out']
+        return (op['bn'] and x in self.graph.inputs.values() and op['ksize'] == 3 and op['cin'] == 3 and self.act[x][1] == 8 and op['cout'] == 32
+                and out in self.fused_pool and self.act[self.fused_pool[out]['out']][1] >= 32 and x.h % 2 == 0 and x.w % 2 == 0
+                and (not self.training or self.fuse_bn_stats))
 
     def _fin_limit(self, C):
         """Most partial rows a reduce_part launch may leave for a *_fin consumer with C channels (0: the shape does not qualify)."""

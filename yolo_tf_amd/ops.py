@@ -376,6 +376,26 @@ def l2_regularizer(w, g, n, scale, loss):
     call('yolo2_l2_regularizer', ptr(w), ptr(g), n, scale, ptr(loss), _stream())
 
 
+# ---- image layer fused with its consumers (include/yolo2_hip.h: yolo2_first_layer_*)
+def first_layer_stats(P, F, B, H, W, shift, bn_part):
+    call('yolo2_first_layer_stats', ptr(P), ptr(F), B, H, W, ptr(shift), ptr(bn_part), dtype_code(P.dtype), _stream())
+
+
+def first_layer_bn_leaky_pool(P, F, mean, var, gamma, beta, Pout, idx, B, H, W, ldp, eps, alpha):
+    call('yolo2_first_layer_bn_leaky_pool', ptr(P), ptr(F), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(Pout), ptr(idx), B, H, W, ldp, eps, alpha,
+         dtype_code(P.dtype), _stream())
+
+
+def first_layer_pool_bwd_reduce(P, F, dP, lddp, idx, mean, var, gamma, beta, bn_part, B, H, W, eps, alpha):
+    call('yolo2_first_layer_pool_bwd_reduce', ptr(P), ptr(F), ptr(dP), lddp, ptr(idx), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(bn_part), B, H, W,
+         eps, alpha, dtype_code(P.dtype), _stream())
+
+
+def first_layer_pool_bwd_apply(P, F, dP, lddp, idx, mean, var, gamma, beta, dgamma, dbeta, dY, B, H, W, eps, alpha):
+    call('yolo2_first_layer_pool_bwd_apply', ptr(P), ptr(F), ptr(dP), lddp, ptr(idx), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(dgamma), ptr(dbeta),
+         ptr(dY), B, H, W, eps, alpha, dtype_code(P.dtype), _stream())
+
+
 # ---- data-parallel support
 def set_stream_workgroups(n):
     """Stream-K convolution launches use ``n`` workgroups instead of one per CU (0 = default)."""
