@@ -49,6 +49,25 @@ def layer_end_offsets(graph, offsets):
     return ends
 
 
+_SKEW_KB = int(os.environ.get('YOLO2_ALLOC_SKEW_KB', '20'))
+_skew_counter = [0]
+
+
+def staggered(n, dtype, device, fill=0.0):
+    """A device buffer of ``n`` elements whose start is offset by (k mod 16) x 20 KiB from its allocation, k counting the big buffers of the
+    process.  The caching allocator hands out 2 MiB-aligned blocks, so equally sized arenas that one kernel walks in lock step (Adam reads
+    element i of four of them at once; a filter gradient reads pixel m of x and dY) otherwise sit at identical offsets of the HBM
+    channel interleave: measured 418 us for the Adam pass with 2 MiB-aligned arenas against 377 us with 4 KiB of stagger; whole step +0.5..0.8 % with 4-68 KiB, best at 20
+    (scripts/arena_alias_bench.py, profiles/r03_arena_stagger.txt).  YOLO2_ALLOC_SKEW_KB=0 switches it off (A/B)."""
+    esz = torch.empty(0, dtype=dtype).element_size()
+    if _SKEW_KB <= 0 or n * esz < (1 << 20):
+        return torch.full((n,), fill, dtype=dtype, device=device) if fill else torch.zeros(n, dtype=dtype, device=device)
+    k = _skew_counter[0] = _skew_counter[0] + 1
+    skew = (k % 16) * _SKEW_KB * 1024 // esz
+    base = torch.full((n + 16 * _SKEW_KB * 1024 // esz,), fill, dtype=dtype, device=device) if fill else torch.zeros(n + 16 * _SKEW_KB * 1024 // esz, dtype=dtype, device=device)
+    return base[skew:skew + n]
+
+
 class _PartPool(object):
     """Host-side bookkeeping of the partial-row buffers (stream order = call order on the main stream).  A producer takes a CLEAN
     buffer; its consumer marks it USED and hands one earlier USED buffer to its own kernel to clear (``take_to_zero``)."""
@@ -116,8 +135,8 @@ class Engine(object):
         other = [v for v in g.variables.values() if not v.trainable]
         self.param_offsets, off = layout_params(g)
         self.n_params = off
-        self.params = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grads = torch.zeros(off, dtype=torch.float32, device=self.device) if self.training else None
+        self.params = staggered(off, torch.float32, self.device)
+        self.grads = staggered(off, torch.float32, self.device) if self.training else None
         self.state_offsets = {}
         off = 0
         for v in other:
@@ -171,9 +190,9 @@ class Engine(object):
         self._roots, self._groots = {}, {}
         for t in self.graph.tensors:
             if t.base is None:
-                self._roots[t.name] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
+                self._roots[t.name] = staggered(B * t.h * t.w * t.ld, T, dev)
                 if self.training and t not in self.graph.inputs.values():
-                    self._groots[t.name] = torch.zeros(B * t.h * t.w * t.ld, dtype=T, device=dev)
+                    self._groots[t.name] = staggered(B * t.h * t.w * t.ld, T, dev)
         self.conv = {}
         max_y = 0
         max_c = 8
@@ -182,9 +201,9 @@ class Engine(object):
                 continue
             k, cin, cout = op['ksize'], op['cin'], op['cout']
             cp, ldy = pad8(cin), pad8(cout)
-            st = {'Ffwd': torch.zeros(cout * k * k * cp, dtype=T, device=dev)}
+            st = {'Ffwd': staggered(cout * k * k * cp, T, dev)}
             if self.training and op['x'] not in self.graph.inputs.values():
-                st['Fdgr'] = torch.zeros(cin * k * k * ldy, dtype=T, device=dev)
+                st['Fdgr'] = staggered(cin * k * k * ldy, T, dev)
             if op['bn']:
                 st['mean'] = torch.zeros(cout, dtype=torch.float32, device=dev)
                 st['var'] = torch.ones(cout, dtype=torch.float32, device=dev)
@@ -220,7 +239,7 @@ class Engine(object):
         if self.training:
             # dY scratch ring: the filter gradient of layer L runs on a side stream concurrently with the data gradient
             # (and the following layers' backward) on the main stream, so dY(L) must outlive the next layers' writes
-            self.dy_ring = [torch.zeros(max_y, dtype=T, device=dev) for _ in range(3)]
+            self.dy_ring = [staggered(max_y, T, dev) for _ in range(3)]
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
             self.side_stream = torch.cuda.Stream(device=dev)
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)

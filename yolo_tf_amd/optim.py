@@ -51,7 +51,8 @@ class Optimizer(object):
                 if config.has_option(section, key):
                     self.hp[key] = config.getfloat(section, key)
         self.n = n
-        z = lambda fill=0.0: torch.full((n,), fill, dtype=torch.float32, device=device)
+        from .engine import staggered          # (arena placement: see engine.staggered)
+        z = lambda fill=0.0: staggered(n, torch.float32, device, fill)
         self.slots = {
             'adam': lambda: [z(), z()], 'adadelta': lambda: [z(), z()],
             'adagrad': lambda: [z(self.hp.get('initial_accumulator_value', 0.1))], 'momentum': lambda: [z()],
