@@ -27,11 +27,12 @@ def test_arena_layout_is_reverse_creation_order_and_backward_monotone():
     from yolo_tf_amd.engine import layout_params, layer_end_offsets
     g = _graph()
     offsets, total = layout_params(g)
-    assert total >= 67_100_000 and total % 4 == 0
+    from yolo_tf_amd.engine import ARENA_ALIGN
+    assert total >= 67_100_000 and total % ARENA_ALIGN == 0
     spans = sorted(offsets.values())
     assert spans[0][0] == 0
     for (o1, n1), (o2, _) in zip(spans, spans[1:]):
-        assert o1 + (n1 + 3) // 4 * 4 == o2 and o2 % 4 == 0          # contiguous, 16-byte aligned
+        assert o1 + (n1 + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN == o2          # contiguous up to the 256-byte alignment of every variable
     # the last layer's variables come first: their gradients are the first to be final
     assert offsets['yolo2_darknet/conv/biases'][0] < offsets['yolo2_darknet/conv20/weights'][0] < offsets['yolo2_darknet/conv0/weights'][0]
     ends = layer_end_offsets(g, offsets)
@@ -47,7 +48,7 @@ def test_buckets_partition_the_arena_at_variable_boundaries():
         buckets = make_buckets(offsets.values(), total, int(mb * 1024 * 1024 / 4))
         assert buckets[0][0] == 0 and buckets[-1][1] == total
         assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))
-        bounds = {o + (n + 3) // 4 * 4 for o, n in offsets.values()} | {total}
+        bounds = {o for o, n in offsets.values()} | {total}
         assert all(e in bounds for _, e in buckets)
         assert all(e - s >= mb * 1024 * 1024 / 4 for s, e in buckets[:-1])
     assert len(make_buckets(offsets.values(), total, 16 * 1024 * 1024)) >= 3   # 64 MiB buckets: several all-reduces in flight

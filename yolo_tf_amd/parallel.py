@@ -59,8 +59,9 @@ def agree(flags, device):
 
 def make_buckets(offsets_sizes, total, bucket_elems):
     """Splits [0, total) at variable boundaries into contiguous buckets of >= bucket_elems elements
-    (the last one takes the remainder).  ``offsets_sizes``: iterable of (offset, size), any order."""
-    bounds = sorted(o + ((n + 3) // 4 * 4) for o, n in offsets_sizes)
+    (the last one takes the remainder).  ``offsets_sizes``: iterable of (offset, size), any order; a boundary = the start of a variable
+    (the arena may pad between variables: engine.ARENA_ALIGN)."""
+    bounds = sorted({o for o, _ in offsets_sizes if o > 0} | {total})
     buckets, start = [], 0
     for b in bounds:
         if b - start >= bucket_elems:
