@@ -67,19 +67,24 @@ __global__ __launch_bounds__(256) void loss_kernel(
         s1 = (1.0f - mb) * iou_dist;
         const float dc0 = sg[1] - tc[0], dc1 = sg[2] - tc[1], dc2 = sq[0] - tc[2], dc3 = sq[1] - tc[3];
         s2 = mb * (dc0 * dc0) + mb * (dc1 * dc1) + mb * (dc2 * dc2) + mb * (dc3 * dc3);
-        // softmax over classes (two passes over the logits; they are L1-resident)
-        float mx = -INFINITY;
-        for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)lp[5 + k]);
-        float den = 0.f;
-        for (int k = 0; k < C; ++k) den += expf((float)lp[5 + k] - mx);
+        // softmax over classes (two passes over the logits; they are L1-resident).  Only the responsible anchors need it: the class term
+        // and its gradient carry the factor mask_best (model/yolo2/__init__.py:87,94), which is 0 for every other lane -- a handful of
+        // lanes per image instead of all 845 (with 80 classes the three class loops were 2/3 of this kernel: 45 -> 15 us at batch 8).
+        const bool resp = mb != 0.0f;
+        float mx = -INFINITY, den = 1.f;
         const float *tp = prob + cell_id * C;
         float sp = 0.f, dot = 0.f;
         const float gp = 2.0f * mb * w_prob / cnt;
-        for (int k = 0; k < C; ++k) {
-            float p = expf((float)lp[5 + k] - mx) / den;
-            float e = p - tp[k];
-            sp += e * e;
-            dot += (gp * e) * p;
+        if (resp) {
+            for (int k = 0; k < C; ++k) mx = fmaxf(mx, (float)lp[5 + k]);
+            den = 0.f;
+            for (int k = 0; k < C; ++k) den += expf((float)lp[5 + k] - mx);
+            for (int k = 0; k < C; ++k) {
+                float p = expf((float)lp[5 + k] - mx) / den;
+                float e = p - tp[k];
+                sp += e * e;
+                dot += (gp * e) * p;
+            }
         }
         s3 = mb * sp;
         if (dlogits) {
@@ -90,10 +95,14 @@ __global__ __launch_bounds__(256) void loss_kernel(
             dp[2] = (T)(2.0f * mb * dc1 * w_coords / cnt * sg[2] * (1.0f - sg[2]));
             dp[3] = (T)(2.0f * mb * dc2 * w_coords / cnt * sq[0] / 2.0f);
             dp[4] = (T)(2.0f * mb * dc3 * w_coords / cnt * sq[1] / 2.0f);
-            for (int k = 0; k < C; ++k) {
-                float p = expf((float)lp[5 + k] - mx) / den;
-                float d = gp * (p - tp[k]);
-                dp[5 + k] = (T)(p * (d - dot));
+            if (resp) {
+                for (int k = 0; k < C; ++k) {
+                    float p = expf((float)lp[5 + k] - mx) / den;
+                    float d = gp * (p - tp[k]);
+                    dp[5 + k] = (T)(p * (d - dot));
+                }
+            } else {
+                for (int k = 0; k < C; ++k) dp[5 + k] = (T)0.f;
             }
             if (a == 0)
                 for (int k = A * D; k < ld; ++k) dlogits[cell_id * ld + k] = (T)0.f;
