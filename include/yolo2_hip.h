@@ -179,6 +179,10 @@ int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int C, float *
  * The rows are only READ here.  zero / zero_floats (multiple of 4, 16-byte aligned; may be NULL / 0): a float range this launch
  * clears on the side -- the engine keeps two partial buffers and has each consumer clear the one its predecessor finished with, so
  * every producer finds zero rows without a memset launch.  Results equal the two-launch forms up to f64 summation order. */
+/* yolo2_bn_leaky_pool_fin: ymax (optional, [B*(H/2)*(W/2)][C], dense) receives the raw convolution output AT the arg-max of each
+ * window.  Only arg-max positions carry gradient, so the layer's backward reduction is then yolo2_bn_leaky_bwd_reduce_part over
+ * (dP, ymax) at the POOLED resolution: a quarter of the rows, and neither Y nor idx are read.  A_full (optional, dense [B*H*W][C])
+ * also receives the un-pooled activation, for a layer whose activation has a second reader (idx may then be NULL). */
 int yolo2_last_bn_part_rows(void);
 int yolo2_bn_fin_supported(int rows, int C, int dtype);
 int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var, float *moving_mean,
@@ -186,8 +190,8 @@ int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows, const floa
                        float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream);
 int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var,
                             float *moving_mean, float *moving_var, double decay, const float *gamma, const float *beta, void *P,
-                            unsigned char *idx, int B, int H, int W, int C, int ldp, float eps, float alpha, float *zero,
-                            long zero_floats, int dtype, void *stream);
+                            unsigned char *idx, void *ymax, void *A_full, int B, int H, int W, int C, int ldp, float eps, float alpha,
+                            float *zero, long zero_floats, int dtype, void *stream);
 /* part: [2][rows][C] with plane_stride floats between the two planes (YOLO2_BN_PART_ROWS * C for bn_part, rows * C for a ws) */
 int yolo2_bn_leaky_bwd_apply_fin(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
                                  const float *beta, const float *part, int rows, long plane_stride, float *dgamma, float *dbeta,
@@ -276,6 +280,9 @@ int yolo2_maxpool_fwd(const void *A, void *P, int B, int H, int W, int C, int st
                       int dtype, void *stream);
 int yolo2_maxpool_bwd(const void *A, const void *dP, void *dA, int B, int H, int W, int C,
                       int stride, int dtype, void *stream);
+/* dA += the routed gradient, rounded to the element type like yolo2_maxpool_bwd into a temporary + yolo2_add_inplace (stride 2 only):
+ * the second writer of a tensor's gradient (Darknet-19's passthrough fan-out at the 26x26 stage) */
+int yolo2_maxpool_bwd_acc(const void *A, const void *dP, void *dA, int B, int H, int W, int C, int dtype, void *stream);
 
 /* ---- reorg / concat: model/yolo2/function.py:22-29, model/yolo2/inference.py:114-116 ----------
  * out[b,y,x,(sy*2+sx)*C+c] = in[b,2y+sy,2x+sx,c]; `out` has pixel stride ldo so it can be the

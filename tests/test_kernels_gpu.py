@@ -767,9 +767,14 @@ def test_bn_consumers_with_folded_finalisation_vs_oracle(ops, shape, rows, mode)
     P = torch.zeros(MP * C, dtype=tdtype, device='cuda')
     idx = torch.full((MP * C,), 9, dtype=torch.uint8, device='cuda')
     mean2, var2 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    ops.bn_leaky_pool_fin(yd, dev(part), rows, dev(shift), mean2, var2, None, None, 0.999, g, b_, P, idx, B, H, W, C, C, 1e-5, 0.1)
+    ymax = torch.full((MP * C,), 5.0, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_fin(yd, dev(part), rows, dev(shift), mean2, var2, None, None, 0.999, g, b_, P, idx, B, H, W, C, C, 1e-5, 0.1, ymax=ymax)
     torch.cuda.synchronize()
     assert torch.equal(mean2, mean) and torch.equal(var2, var)
+    # ymax = the stored convolution output at the recorded arg-max position, exactly
+    yw = host(yd).reshape(B, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 2, 4, 5).reshape(B, H // 2, W // 2, 4, C)
+    pick = np.take_along_axis(yw, host(idx).reshape(B, H // 2, W // 2, 1, C).astype(np.int64), axis=3)[:, :, :, 0, :]
+    assert np.array_equal(host(ymax).reshape(pick.shape), pick), 'ymax is not y at the arg-max'
     a_st = bf16_round(a_r) if mode == 'bf16' else a_r
     p_r = R.max_pool(a_st, 2)
     assert_close(host(P).reshape(p_r.shape), p_r, rtol, 'bn_leaky_pool_fin')
@@ -792,6 +797,15 @@ def test_bn_consumers_with_folded_finalisation_vs_oracle(ops, shape, rows, mode)
     assert_close(host(dg2), host(dg_ref), 2e-5, 'pooled dgamma')
     assert_close(host(db2), host(db_ref), 2e-5, 'pooled dbeta')
     assert_close(host(dy2), host(dy_ref), 1e-5 if mode == 'f32' else 8e-3, 'pooled dY')
+    # the same sums from (dP, ymax) at the pooled resolution: what the engine runs (neither Y nor idx are read by the reduction)
+    r3 = ops.bn_leaky_bwd_reduce_part(dpd, C, ymax, mean, var, g, b_, ws, limit, MP, C, 1e-5, 0.1)
+    dg4, db4 = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dy4 = torch.full((M * C,), 7.0, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply_fin(dpd, C, idx, yd, mean, var, g, b_, ws, r3, r3 * C, dg4, db4, dy4, B, H, W, C, 1e-5, 0.1)
+    torch.cuda.synchronize()
+    assert_close(host(dg4), host(dg_ref), 2e-5, 'pooled dgamma from ymax')
+    assert_close(host(db4), host(db_ref), 2e-5, 'pooled dbeta from ymax')
+    assert_close(host(dy4), host(dy_ref), 1e-5 if mode == 'f32' else 8e-3, 'pooled dY from ymax')
 
 
 
@@ -819,6 +833,16 @@ def test_maxpool(ops, stride, shape, mode):
         assert_close(host(dA).reshape(shape), ref, 1e-2, 'pool bwd')
     else:
         assert np.array_equal(host(dA).reshape(shape), ref)
+    if stride == 2:
+        # accumulating form (second writer of a gradient): bit-equal to the temporary + yolo2_add_inplace pair it replaces
+        first = bf16_round(rng.randn(*shape))
+        g_pair, g_acc = dev(first, tdtype), dev(first, tdtype)
+        ops.add_inplace(g_pair, dA, dA.numel())
+        ops.maxpool_bwd_acc(dev(a, tdtype), dev(dp, tdtype), g_acc, B, H, W, C)
+        torch.cuda.synchronize()
+        assert torch.equal(g_pair, g_acc)
+        want = first + ref
+        assert_close(host(g_acc).reshape(shape), bf16_round(want) if mode == 'bf16' else want, 1e-6 if mode == 'f32' else 1e-2, 'pool bwd acc')
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])

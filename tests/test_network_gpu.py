@@ -480,6 +480,17 @@ def forward_teacher_forced(e, scope, params0, f32):
                 got_a, ref_a = (read_t(e, pool['out']), R.max_pool(a, 2)) if pool is not None else (read_t(e, op['out']), a)
                 fwd_report.append((rel_l2(got_a, ref_a), name + ' activation'))
                 assert rel(got_a, ref_a) <= tol_fwd and fwd_report[-1][0] <= tol_fwd_l2, '%s activation: max %.3e' % (name, rel(got_a, ref_a))
+                if pool is not None and st.get('ymax_valid'):
+                    # the side output the backward reduction reads: the STORED raw output at the first maximum of each window, exactly
+                    Bq, Hq, Wq, Cq = y.shape
+                    win = lambda t: t.reshape(Bq, Hq // 2, 2, Wq // 2, 2, Cq).transpose(0, 1, 3, 2, 4, 5).reshape(Bq, Hq // 2, Wq // 2, 4, Cq)
+                    got_act = q(R.leaky_relu(R.bn_apply(y, st['mean'].cpu().numpy(), st['var'].cpu().numpy(), params0[name + '/BatchNorm/gamma'], params0[bname])))
+                    arg = np.argmax(win(got_act), axis=3)[:, :, :, None, :]
+                    want = np.take_along_axis(win(y), arg, axis=3)[:, :, :, 0, :]
+                    n = want.size
+                    got_ym = st['pool_ymax'][:n].float().cpu().numpy().reshape(want.shape)
+                    same = float(np.mean(got_ym == want))
+                    assert same >= 0.9999, '%s ymax: %.6f equal' % (name, same)     # (a tie broken by a last-ulp difference of the activation picks the other, equal-activation, position)
             else:
                 ref_o = q(conv + params0[name + '/biases'])
                 assert rel(read_t(e, op['out']), ref_o) <= tol_fwd, name

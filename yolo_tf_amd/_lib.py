@@ -42,7 +42,7 @@ SIGNATURES = {
     'yolo2_conv2d_bn': [_p, _p, _p, _p, ctypes.c_size_t, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p],
     'yolo2_bn_finalize': [_p, _p, _l, _i, _p, _p, _p, _p, ctypes.c_double, _p],
     'yolo2_bn_leaky_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _l, _i, _i, _f, _f, _p, _l, _i, _p],
-    'yolo2_bn_leaky_pool_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_bn_leaky_pool_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _l, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_bwd_reduce_part': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _f, _f, _i, _p],
@@ -60,6 +60,7 @@ SIGNATURES = {
     'yolo2_bn_leaky_bwd_apply': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _f, _f, _i, _p],
     'yolo2_maxpool_fwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_maxpool_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'yolo2_maxpool_bwd_acc': [_p, _p, _p, _i, _i, _i, _i, _i, _p],
     'yolo2_reorg': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'yolo2_reorg_bwd': [_p, _i, _p, _i, _i, _i, _i, _i, _p],
     'yolo2_copy_channels': [_p, _i, _p, _i, _l, _i, _i, _p],

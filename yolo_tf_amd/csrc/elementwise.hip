@@ -905,8 +905,8 @@ template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__ Y, const float *__restrict__ part, int rows, const float *__restrict__ shift,
                                                            long Mstat, float *__restrict__ mean_out, float *__restrict__ var_out, float *__restrict__ mm,
                                                            float *__restrict__ mv, float omd, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                           T *__restrict__ A, unsigned char *__restrict__ idx, int B, int H, int W, int C, int lda, float eps,
-                                                           float alpha, float *__restrict__ zero, long zero_vec4) {
+                                                           T *__restrict__ A, unsigned char *__restrict__ idx, T *__restrict__ ymax, T *__restrict__ Afull,
+                                                           int B, int H, int W, int C, int lda, float eps, float alpha, float *__restrict__ zero, long zero_vec4) {
     constexpr int N = Vec16<T>::N;
     const SliceMap sm(C, N);
     __shared__ double sums[2][Y2_SLICE_MAX];
@@ -975,6 +975,7 @@ __global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__
             st16(A + r * lda + sm.cg * N, o);
         } else {
             typename IdxPack<N>::type pack = 0;
+            Vec16<T> ym, af[4];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float a[4];
@@ -982,14 +983,24 @@ __global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__
                 for (int k = 0; k < 4; ++k) {
                     const float z = (v[POOL ? k : 0].get(j) - mu[j]) * sc[j] + bt[j];
                     a[k] = (float)(T)fmaxf(z, alpha * z);
+                    af[k].set(j, a[k]);
                 }
                 const float m = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
                 const int arg = a[0] == m ? 0 : a[1] == m ? 1 : a[2] == m ? 2 : 3;
                 o.set(j, m);
+                ym.set(j, arg == 0 ? v[0].get(j) : arg == 1 ? v[POOL ? 1 : 0].get(j) : arg == 2 ? v[POOL ? 2 : 0].get(j) : v[POOL ? 3 : 0].get(j));
                 pack |= (typename IdxPack<N>::type)arg << (8 * j);
             }
             st16(A + r * lda + sm.cg * N, o);
             if (idx) *reinterpret_cast<typename IdxPack<N>::type *>(idx + r * C + sm.cg * N) = pack;
+            if (Afull) {       // the activation has another reader besides the pool (Darknet-19's passthrough at the 26x26 stage): dense [B][H][W][C]
+                T *dst = Afull + pr.base(r) + sm.cg * N;
+                st16(dst, af[0]);
+                st16(dst + C, af[1]);
+                st16(dst + (long)W * C, af[2]);
+                st16(dst + (long)W * C + C, af[3]);
+            }
+            if (ymax) st16(ymax + r * C + sm.cg * N, ym);       // the raw convolution output at the arg-max (the backward reduction reads this, not Y)
         }
 #pragma unroll
         for (int k = 0; k < (POOL ? 4 : 1); ++k) v[k] = vn[k];
@@ -1120,8 +1131,8 @@ __global__ void maxpool_fwd_kernel(const T *__restrict__ A, T *__restrict__ P, i
 }
 
 // stride 2: one thread per pooled chunk writes all four input positions (full overwrite of dA)
-template <typename T>
-__global__ void maxpool_bwd_s2_kernel(const T *__restrict__ A, const T *__restrict__ dP, T *__restrict__ dA, int B, int H, int W, int C) {
+template <typename T, bool ACC>      // ACC: dA += (a second writer of the tensor's gradient: passthrough fan-out), rounded to T like a separate add
+__global__ void maxpool_bwd_s2_kernel(const T *__restrict__ A, const T *__restrict__ dP, T *dA, int B, int H, int W, int C) {
     constexpr int N = Vec16<T>::N;
     const int OH = H / 2, OW = W / 2, cgs = C / N;
     const long total = (long)B * OH * OW * cgs;
@@ -1139,12 +1150,18 @@ __global__ void maxpool_bwd_s2_kernel(const T *__restrict__ A, const T *__restri
         v[2] = ld16(A + base + (long)W * C);
         v[3] = ld16(A + base + (long)W * C + C);
         Vec16<T> g = ld16(dP + p * C + cg * N);
+        if (ACC) {
+            o[0] = ld16(dA + base);
+            o[1] = ld16(dA + base + C);
+            o[2] = ld16(dA + base + (long)W * C);
+            o[3] = ld16(dA + base + (long)W * C + C);
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float m = fmaxf(fmaxf(v[0].get(j), v[1].get(j)), fmaxf(v[2].get(j), v[3].get(j)));
             int arg = v[0].get(j) == m ? 0 : v[1].get(j) == m ? 1 : v[2].get(j) == m ? 2 : 3;  // first max in scan order
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k].set(j, k == arg ? g.get(j) : 0.f);
+            for (int k = 0; k < 4; ++k) o[k].set(j, (ACC ? o[k].get(j) : 0.f) + (k == arg ? g.get(j) : 0.f));
         }
         st16(dA + base, o[0]);
         st16(dA + base + C, o[1]);
@@ -1228,11 +1245,22 @@ extern "C" int yolo2_maxpool_bwd(const void *A, const void *dP, void *dA, int B,
     hipStream_t st = (hipStream_t)stream;
     if (stride == 2) {
         long total = (long)B * (H / 2) * (W / 2) * (C / vec);
-        Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s2_kernel<T><<<ew_grid(total), 256, 0, st>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
+        Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s2_kernel<T, false><<<ew_grid(total), 256, 0, st>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
     } else {
         long total = (long)B * H * W * (C / vec);
         Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s1_kernel<T><<<ew_grid(total), 256, 0, st>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
     }
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
+// dA += the routed gradient (stride 2): yolo2_maxpool_bwd into a temporary + yolo2_add_inplace in one launch, same rounding
+extern "C" int yolo2_maxpool_bwd_acc(const void *A, const void *dP, void *dA, int B, int H, int W, int C, int dtype, void *stream) {
+    Y2_CHECK_ARG(A && dP && dA && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0);
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    Y2_CHECK_ARG(C % vec == 0);
+    long total = (long)B * (H / 2) * (W / 2) * (C / vec);
+    Y2_DISPATCH_DTYPE(dtype, maxpool_bwd_s2_kernel<T, true><<<ew_grid(total), 256, 0, (hipStream_t)stream>>>((const T *)A, (const T *)dP, (T *)dA, B, H, W, C));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -1820,14 +1848,15 @@ extern "C" int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows,
     Y2_CHECK_ARG(lda % vec == 0);
     const dim3 grid = slice_grid(M, C, vec, 4, rows);
     Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, M, mean, var, moving_mean, moving_var,
-                      (float)(1.0 - decay), gamma, beta, (T *)A, nullptr, 1, 1, (int)M, C, lda, eps, alpha, zero, zero_floats / 4));
+                      (float)(1.0 - decay), gamma, beta, (T *)A, nullptr, nullptr, nullptr, 1, 1, (int)M, C, lda, eps, alpha, zero, zero_floats / 4));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
 
 extern "C" int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int rows, const float *shift, float *mean, float *var, float *moving_mean,
-                                       float *moving_var, double decay, const float *gamma, const float *beta, void *P, unsigned char *idx, int B, int H,
-                                       int W, int C, int ldp, float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream) {
+                                       float *moving_var, double decay, const float *gamma, const float *beta, void *P, unsigned char *idx, void *ymax,
+                                       void *A_full, int B, int H, int W, int C, int ldp, float eps, float alpha, float *zero, long zero_floats, int dtype,
+                                       void *stream) {
     Y2_CHECK_ARG(Y && bn_part && shift && mean && var && gamma && beta && P && ldp >= C);
     Y2_CHECK_ARG(pool_args_ok(B, H, W, C, dtype) && ldp % (dtype == YOLO2_BF16 ? 8 : 4) == 0);
     Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr) && rows <= Y2_BN_PART_ROWS && fin_shape_ok(rows, C, dtype));
@@ -1835,7 +1864,7 @@ extern "C" int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int 
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     const dim3 grid = slice_grid((long)B * (H / 2) * (W / 2), C, vec, 2, rows);
     Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin_kernel<T, true><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, (long)B * H * W, mean, var, moving_mean,
-                      moving_var, (float)(1.0 - decay), gamma, beta, (T *)P, idx, B, H, W, C, ldp, eps, alpha, zero, zero_floats / 4));
+                      moving_var, (float)(1.0 - decay), gamma, beta, (T *)P, idx, (T *)ymax, (T *)A_full, B, H, W, C, ldp, eps, alpha, zero, zero_floats / 4));
     Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
@@ -1878,6 +1907,14 @@ extern "C" int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const vo
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
     int nb = colsum_grid(M, C, vec);
+    // > 32 MB to read (the pooled 208x208 / 104x104 stages): one workgroup per CU is latency-bound, as for the pooled reduction above
+    static const int big = getenv("YOLO2_REDUCE_PART_BLOCKS") ? atoi(getenv("YOLO2_REDUCE_PART_BLOCKS")) : 1024;
+    if (big > nb && M * C * (16 / vec) * 2 >= (32L << 20)) {
+        const int tpr = C / vec, rpp = 256 / tpr < 1 ? 1 : 256 / tpr;
+        const long g = (M + (long)rpp * 16 - 1) / ((long)rpp * 16);
+        nb = (int)(g < big ? g : big);
+        if (nb > 1024) nb = 1024;
+    }
     if (nb > rows_limit) nb = rows_limit;
     Y2_DISPATCH_DTYPE(dtype, bn_bwd_reduce_kernel<T><<<nb, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, (float *)ws, M, C, eps, alpha));
     Y2_CHECK_LAUNCH();

@@ -217,6 +217,8 @@ class Engine(object):
             max_c = max(max_c, ldy)
         self._bindings = {}
         self._tmp_roots = {}
+        self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0'
+        self.pool_ymax = self.fold_finalize and os.environ.get('YOLO2_POOL_YMAX', '1') != '0'
         self._bind(self.graph)
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
@@ -225,7 +227,6 @@ class Engine(object):
         # (_PartPool below) -- no finalisation launch, no memset launch.  YOLO2_FOLD_FINALIZE=0: separate finalisation kernels (A/B).
         self.parts = _PartPool(3, 2 * 256 * max(max_c, 8), dev)
         self.bn_part = self.parts.bufs[0]                       # (kept for callers that drive the two-launch form directly)
-        self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0'
         # image layer recomputed inside its consumers instead of stored: 'infer' (default: detect only -- batch 256: 12.5 -> 11.3 ms),
         # '1' (training too: measured neutral, the recomputing backward kernels are VALU-bound -- profiles/r03_first_layer_fused.md), '0' never
         self.fuse_first = os.environ.get('YOLO2_FUSE_FIRST', 'infer')
@@ -264,7 +265,7 @@ class Engine(object):
                 gact[t] = (self._groots[r.name][off:], ld)
         # BN + leaky + max-pool fusion: a batch-normalised conv whose output feeds one stride-2 pool and nothing else never
         # materialises its full-resolution activation (forward) or that activation's gradient (backward)
-        fused_pool = {}
+        fused_pool, fwd_pool = {}, {}
         if os.environ.get('YOLO2_FUSE_POOL', '1') != '0':
             uses = {}
             for op in graph.ops:
@@ -281,6 +282,18 @@ class Engine(object):
                     need = B * (x.h // 2) * (x.w // 2) * x.c
                     if self.training and ('pool_idx' not in st or st['pool_idx'].numel() < need):
                         st['pool_idx'] = torch.zeros(need, dtype=torch.uint8, device=dev)
+                    # the raw output AT the arg-max, a quarter of y: all the layer's backward reduction needs (YOLO2_POOL_YMAX=0: A/B)
+                    if self.training and self.pool_ymax and ('pool_ymax' not in st or st['pool_ymax'].numel() < need):
+                        st['pool_ymax'] = staggered(need, T, dev)
+            # forward only: the pool of an activation that has OTHER readers too (Darknet-19's 26x26 passthrough) still comes out of the BN
+            # pass, which then stores both resolutions (yolo2_bn_leaky_pool_fin, A_full); the backward keeps the separate kernels
+            for op in graph.ops:
+                x = op.get('x')
+                if (self.training and op['kind'] == 'pool' and op['stride'] == 2 and x in producers and producers[x]['bn'] and x not in fused_pool
+                        and uses.get(x, 0) > 1 and x.h % 2 == 0 and x.w % 2 == 0 and act[x][1] == x.c and act[op['out']][1] == op['out'].c
+                        and act[producers[x]['y']][1] == x.c and x.c // (8 if T == torch.bfloat16 else 4) <= 256
+                        and os.environ.get('YOLO2_FUSE_POOL_FANOUT', '1') != '0'):
+                    fwd_pool[x] = op
         # BN-backward sums in the consumer's data-gradient epilogue: a batch-normalised conv whose full-resolution activation has
         # exactly one reader, a convolution writing that activation's gradient directly (no concat slice, no fan-out)
         bn_bwd_fused = {}
@@ -301,7 +314,7 @@ class Engine(object):
                     bn_bwd_fused[op['name']] = producers[x]
         inp = next(iter(graph.inputs.values()))
         self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {},
-                                          'bn_bwd_fused': bn_bwd_fused}
+                                          'bn_bwd_fused': bn_bwd_fused, 'fwd_pool': fwd_pool}
         self._use(inp.h, inp.w)
 
     def _use(self, h, w):
@@ -309,7 +322,7 @@ class Engine(object):
         self._cur = bnd
         self.graph, self.act, self.gact, self.fused_pool = bnd['graph'], bnd['act'], bnd['gact'], bnd['fused_pool']
         self._zero_ranges, self.tmp_grad = bnd['zero_ranges'], bnd['tmp_grad']
-        self.bn_bwd_fused = bnd['bn_bwd_fused']
+        self.bn_bwd_fused, self.fwd_pool = bnd['bn_bwd_fused'], bnd['fwd_pool']
 
     def add_size(self, graph):
         """Multi-scale training (BASELINE configs[3]): binds another traced input size of the SAME network (same variables, any
@@ -471,6 +484,7 @@ class Engine(object):
     def forward(self):
         self._prepare_filters()
         B = self.B
+        pooled = set()               # pool ops already produced by their producer's BN pass in this sweep
         for op in self.graph.ops:
             kind = op['kind']
             if kind == 'conv':
@@ -527,7 +541,13 @@ class Engine(object):
                         if pool is not None:
                             pb, ldp = self.act[pool['out']]
                             ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, st.get('pool_idx'),
-                                                  B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                                                  B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn, ymax=st.get('pool_ymax'))
+                            st['ymax_valid'] = 'pool_ymax' in st
+                        elif out in self.fwd_pool:        # both resolutions from one pass (the activation has a second reader)
+                            pb, ldp = self.act[self.fwd_pool[out]['out']]
+                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, None,
+                                                  B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn, a_full=self.act[out][0])
+                            pooled.add(self.fwd_pool[out]['name'])
                         else:
                             ob, ldo = self.act[out]
                             ops.bn_leaky_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, ob, M, op['cout'], ldo,
@@ -536,6 +556,7 @@ class Engine(object):
                     elif pool is not None:
                         pb, ldp = self.act[pool['out']]
                         ops.bn_leaky_pool(yb, mean, var, gamma, beta, pb, st.get('pool_idx'), B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA)
+                        st['ymax_valid'] = False
                     else:
                         ob, ldo = self.act[out]
                         ops.bn_leaky(yb, mean, var, gamma, beta, ob, M, op['cout'], ldo, BN_EPS, LEAKY_ALPHA)
@@ -557,7 +578,7 @@ class Engine(object):
                 ops.dropout(self.act[x][0], self.act[out][0], mask, n, op['keep_prob'], 0 if fixed else self._dropout_seed_for(op))
             elif kind == 'pool':
                 x, out = op['x'], op['out']
-                if x in self.fused_pool:
+                if x in self.fused_pool or op['name'] in pooled:
                     continue                 # produced by the conv's fused BN + leaky + pool pass
                 assert self.act[x][1] == x.c and self.act[out][1] == out.c
                 ops.maxpool_fwd(self.act[x][0], self.act[out][0], B, x.h, x.w, x.c, op['stride'])
@@ -633,7 +654,12 @@ class Engine(object):
                         self.parts.consumed(part, cleared=True)
                     elif pool is not None:      # gradient arrives at the POOLED resolution; routed through the stored arg-max
                         dpb, lddp = self.gact[pool['out']]
-                        if limit >= 128:
+                        if limit >= 64 and st.get('ymax_valid'):
+                            # only arg-max positions carry gradient: the sums over (dP, y at the arg-max) ARE the layer's sums
+                            rows = ops.bn_leaky_bwd_reduce_part(dpb, lddp, st['pool_ymax'], st['mean'], st['var'], gamma, beta, self.ws, limit,
+                                                                M // 4, cout, BN_EPS, LEAKY_ALPHA)
+                            pfin = (self.ws, rows, rows * cout)
+                        elif limit >= 128:
                             rows = ops.bn_leaky_pool_bwd_reduce_part(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, self.ws, limit,
                                                                      B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
                             pfin = (self.ws, rows, rows * cout)
@@ -724,6 +750,10 @@ class Engine(object):
                 x, out = op['x'], op['out']
                 if x in self.fused_pool:
                     continue                 # routed inside the producer's fused BN backward
+                if x in written and op['stride'] == 2 and self.gact[x][1] == x.c:
+                    # second writer of this gradient (the passthrough branch wrote first): accumulate in place, one launch
+                    ops.maxpool_bwd_acc(self.act[x][0], self.gact[out][0], self.gact[x][0], B, x.h, x.w, x.c)
+                    continue
                 dst, ldd, fin = self._grad_sink(x, written)
                 assert ldd == x.c
                 ops.maxpool_bwd(self.act[x][0], self.gact[out][0], dst, B, x.h, x.w, x.c, op['stride'])

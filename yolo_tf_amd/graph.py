@@ -220,15 +220,6 @@ def identity(net, name):
     return net
 
 
-def reorg(net, stride=2, name='reorg'):
-    """model/yolo2/function.py:22-29 (space-to-depth, stride 2)."""
-    assert stride == 2 and net.h % 2 == 0 and net.w % 2 == 0
-    g = net.graph
-    out = g.tensor(name, net.h // 2, net.w // 2, net.c * 4)
-    g.add({'kind': 'reorg', 'name': name, 'inputs': [net], 'x': net, 'out': out})
-    return out
-
-
 def concat(values, axis=3, name='concat'):
     """tf.concat on channels (model/yolo2/inference.py:116): no data movement -- the operands are
     re-homed as channel slices of one buffer, so their producers write straight into it."""

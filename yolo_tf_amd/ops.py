@@ -128,10 +128,10 @@ def bn_leaky_fin(Y, bn_part, rows, shift, mean, var, mm, mv, decay, gamma, beta,
          M, C, lda, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
 
 
-def bn_leaky_pool_fin(Y, bn_part, rows, shift, mean, var, mm, mv, decay, gamma, beta, P, idx, B, H, W, C, ldp, eps, alpha, zero=None, zero_floats=0):
+def bn_leaky_pool_fin(Y, bn_part, rows, shift, mean, var, mm, mv, decay, gamma, beta, P, idx, B, H, W, C, ldp, eps, alpha, zero=None, zero_floats=0, ymax=None, a_full=None):
     z, zn = _zero_args(zero, zero_floats)
     call('yolo2_bn_leaky_pool_fin', ptr(Y), ptr(bn_part), rows, ptr(shift), ptr(mean), ptr(var), ptr(mm), ptr(mv), decay, ptr(gamma), ptr(beta),
-         ptr(P), ptr(idx), B, H, W, C, ldp, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+         ptr(P), ptr(idx), ptr(ymax), ptr(a_full), B, H, W, C, ldp, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
 
 
 def bn_leaky_bwd_apply_fin(dA, ldda, Y, mean, var, gamma, beta, part, rows, plane_stride, dgamma, dbeta, dY, M, C, eps, alpha, zero=None, zero_floats=0):
@@ -183,6 +183,10 @@ def maxpool_fwd(A, P, B, H, W, C, stride):
 
 def maxpool_bwd(A, dP, dA, B, H, W, C, stride):
     call('yolo2_maxpool_bwd', ptr(A), ptr(dP), ptr(dA), B, H, W, C, stride, dtype_code(A.dtype), _stream())
+
+
+def maxpool_bwd_acc(A, dP, dA, B, H, W, C):
+    call('yolo2_maxpool_bwd_acc', ptr(A), ptr(dP), ptr(dA), B, H, W, C, dtype_code(A.dtype), _stream())
 
 
 def reorg(x, out, B, H, W, C, ldo):
