@@ -164,7 +164,9 @@ def test_wgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     if plan['BC'] > 0:
         assert bool(plan['direct']) == (not accumulates), plan
     if name == 'conv8_10_12' and B == 16:
-        assert plan['BC'] == 128 and plan['remap'] == 1 and plan['direct'] == 0, plan      # XCD-local atomic plan
+        assert plan['BC'] == 128 and plan['direct'] == 0, plan                              # 128-wide tile, atomic plan ...
+        if 'YOLO2_WGRAD_BLOCKS' not in os.environ:
+            assert plan['blocks'] <= 7 * torch.cuda.get_device_properties(0).multi_processor_count // 4, plan      # ... all blocks resident at once
 
 
 @pytest.mark.parametrize('name,cin', [('conv18_19', 1024), ('conv20', 3072)])

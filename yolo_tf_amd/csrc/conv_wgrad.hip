@@ -392,21 +392,27 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     p.tiles = tgroups * CT * NT;
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
     static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
-    const int max_ks = cdiv(M, 8 * BKP);                      // keep >= 8 reduction tiles per block
+    // 128-wide tile (8 waves, two workgroups per CU): every block of the grid should be resident at once -- AT MOST 7/4 blocks per CU --
+    // and keep >= 40 reduction tiles, else the 64 KB atomic epilogue and the ring prologue dominate.  26x26 256->512 (72 tiles),
+    // profiles/r03_wgrad_split_sweep.txt: 8 ranges = 576 blocks 55.7 us, 6 = 432 blocks 49.6 us at batch 16; 42.2 -> 34.3 us at batch 8
+    // with 4; 84.8 -> 79.6 us at batch 32 with 6.  64-wide tile: >= 8 reduction tiles per block.
+    static const int resident = getenv("YOLO2_WGRAD_RESIDENT") ? atoi(getenv("YOLO2_WGRAD_RESIDENT")) : 1;      // A/B: 0 = ~512 blocks, >= 8 reduction tiles
+    const bool res = BC >= 128 && resident && env_target <= 0;
+    const int max_ks = res ? (M / (40 * BKP) > 1 ? M / (40 * BKP) : 1) : cdiv(M, 8 * BKP);
     // 64-wide tile: ~1024 blocks for the 3x3 layers, ~384 for the 1x1 layers (9x fewer tiles: more, shorter pixel ranges only add
     // atomic traffic; measured 19.6 -> 15.3 us on the 26x26 1x1 layers)
-    const int def_target = BC >= 128 ? 512 : (ksize == 1 ? 384 : 1024);
+    const int def_target = BC >= 128 ? (res ? 448 : 512) : (ksize == 1 ? 384 : 1024);
     int target = env_target > 0 ? env_target : def_target;
-    int ks = cdiv(target, p.tiles);
+    int ks = res ? (target / p.tiles > 1 ? target / p.tiles : 1) : cdiv(target, p.tiles);
     int remap = env_remap >= 0 ? env_remap : (ks >= 8 && max_ks >= 8);
     if (remap) {
-        ks = cdiv(ks, 8) * 8;
+        ks = res ? ks / 8 * 8 : cdiv(ks, 8) * 8;
         if (ks > max_ks) ks = max_ks / 8 * 8;
         if (ks < 8) remap = 0;
     }
     if (!remap) {
         if (env_target <= 0) target = def_target;
-        ks = cdiv(target, p.tiles);
+        ks = res ? (target / p.tiles > 1 ? target / p.tiles : 1) : cdiv(target, p.tiles);
         if (ks > max_ks) ks = max_ks;
     }
     // a tile grid that already covers the chip takes ONE pixel range: no atomics, plain stores (measured: the atomic epilogue
