@@ -872,6 +872,26 @@ def test_reorg_bit_exact(ops, golden_dir, mode):
         assert np.unique(o2[:, :, i, :]).tolist() == [float(g['reorg/kat_channel_values'][i])]
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,C,ld', [(2704, 125, 128), (1352, 425, 432), (8192, 30, 32), (8193, 30, 32), (40000, 125, 128), (5, 8, 8)])
+def test_bias_grad_both_forms(ops, M, C, ld, mode):
+    """yolo2_bias_grad: the single-launch form (<= 8192 rows: the detection heads of the bench) and the two-stage form, vs the oracle's column sum."""
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    rng = np.random.RandomState(M + C)
+    dy = np.zeros((M, ld), np.float32)
+    dy[:, :C] = rng.randn(M, C) * (1.0 + np.arange(C) % 7)
+    if mode == 'bf16':
+        dy = bf16_round(dy)
+    db = torch.full((C + 3,), 7.0, device='cuda')
+    ws = torch.zeros(1024 * ld, dtype=torch.float64, device='cuda')
+    ops.bias_grad(dev(dy, tdtype), ld, db, ws, M, C)
+    torch.cuda.synchronize()
+    ref = dy[:, :C].astype(np.float64).sum(0)
+    got = host(db)
+    assert np.all(got[C:] == 7.0), 'wrote past C'
+    assert float(np.abs(got[:C] - ref).max()) <= 5e-6 * float(np.abs(dy).sum(0).max()) + 1e-6
+
+
 def test_copy_add_biasgrad(ops):
     rng = np.random.RandomState(1)
     M, C = 338, 125

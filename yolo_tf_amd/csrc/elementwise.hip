@@ -480,6 +480,44 @@ __global__ void colsum_wide_kernel(const T *__restrict__ dY, int ld, long M, int
     dbias[c] = (float)acc;
 }
 
+// few rows (the detection head: 13x13 cells x batch): ONE launch, a workgroup per 16-byte channel group; every thread sums every 256th
+// row in f32 (a handful of rows), the 256 partials meet in f64 through LDS.  The two-stage form costs a second 5 us launch here.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_direct_kernel(const T *__restrict__ dY, int ld, long M, int C, float *__restrict__ dbias) {
+    constexpr int N = Vec16<T>::N;
+    const T *col = dY + (long)blockIdx.x * N;
+    float acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.f;
+    long r = threadIdx.x;
+    for (; r + 768 < M; r += 1024) {       // four independent 16-byte loads in flight
+        Vec16<T> v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld16(col + (r + 256 * u) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] += v[u].get(j);
+    }
+    for (; r < M; r += 256) {
+        const Vec16<T> v = ld16(col + r * ld);
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[j] += v.get(j);
+    }
+    __shared__ double red[256][N + 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) red[threadIdx.x][j] = (double)acc[j];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+#pragma unroll
+            for (int j = 0; j < N; ++j) red[threadIdx.x][j] += red[threadIdx.x + s][j];
+        __syncthreads();
+    }
+    const int c = blockIdx.x * N + threadIdx.x;
+    if ((int)threadIdx.x < N && c < C) dbias[c] = (float)red[0][threadIdx.x];
+}
+
 extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws, long M, int C, int dtype, void *stream) {
     Y2_CHECK_ARG(dY && dbias && ws && M > 0 && C > 0 && ld >= C);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
@@ -491,6 +529,12 @@ extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws,
         return YOLO2_OK;
     }
     Y2_CHECK_ARG(ld % vec == 0);
+    static const long direct_rows = getenv("YOLO2_BIAS_GRAD_DIRECT_ROWS") ? atol(getenv("YOLO2_BIAS_GRAD_DIRECT_ROWS")) : 8192;
+    if (M <= direct_rows && ((uintptr_t)dY & 15) == 0) {
+        Y2_DISPATCH_DTYPE(dtype, colsum_direct_kernel<T><<<cdiv(C, vec), 256, 0, st>>>((const T *)dY, ld, M, C, dbias));
+        Y2_CHECK_LAUNCH();
+        return YOLO2_OK;
+    }
     // reduce over the padded width ld (padding lanes are zero by contract), report the first C
     const int nb = colsum_grid(M, ld, vec);
     float *part = (float *)ws;
