@@ -789,3 +789,33 @@ def test_tensorflow_checkpoint_and_event_file_round_trip(basedir, tmp_path):
         assert all(np.array_equal(got[k], ref3[k]) for k in got) and set(got) <= set(ref)
     finally:
         del os.environ['YOLO2_FUSE_BN_STATS']
+
+
+@pytest.mark.parametrize('B,sizes', [(16, [416]), (8, [416]), (4, [416]), (8, [320, 384, 480, 544, 608])])
+def test_no_layer_falls_back_to_separate_finalisation(basedir, B, sizes, monkeypatch):
+    """Every batch-normalised layer of a Darknet-19 training step takes the consumers that finish the statistics / dgamma, dbeta sums in
+    their own prologue -- at the bench's batch AND at the smaller per-GPU batches of the strong-scaling split and the multi-scale sizes
+    (at batch 8 the 26x26 stage once produced more unique partial rows than its consumer reads and silently took the two-launch form)."""
+    from yolo_tf_amd import ops
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    if os.environ.get('YOLO2_FOLD_FINALIZE', '1') == '0' or os.environ.get('YOLO2_FUSE_BN_STATS', '1') == '0':
+        pytest.skip('folded finalisation switched off')
+    b, _ = make_builder('darknet', 20, max(sizes), True, basedir)
+    sess = TrainSession(b, B, dtype='bf16', optimizer='adam', learning_rate=1e-4, seed=3, sizes=[(s_, s_) for s_ in sizes] if len(sizes) > 1 else None)
+    calls = []
+    for name in ('bn_finalize', 'bn_part_to_grads', 'bn_leaky', 'bn_leaky_pool', 'bn_leaky_bwd_apply', 'bn_leaky_pool_bwd_apply', 'bn_stats_ema'):
+        orig = getattr(ops, name)
+        monkeypatch.setattr(ops, name, (lambda o, n: (lambda *a, **k: (calls.append(n), o(*a, **k))[1]))(orig, name))
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for size in sizes:
+        if len(sizes) > 1:
+            sess.set_size(size, size)
+        sess.upload_labels(data.synthetic_batch(B, 20, size // 32, size // 32, seed=size))
+        sess.step(torch.rand(B, size, size, 3, device='cuda', generator=g) * 255)
+        torch.cuda.synchronize()
+        # (fewer pixels in the last stage than the batch-8 bench shape: its 1x1 layers run K-sliced data gradients, which have no on-chip
+        #  tile to take the producer's sums from; the library then runs reduce + finalise itself and the plain apply pass follows -- by design)
+        allowed = {'bn_leaky_bwd_apply'} if B * (size // 32) ** 2 < 8 * 13 * 13 else set()
+        assert set(calls) <= allowed, (B, size, sorted(set(calls)))
+        del calls[:]

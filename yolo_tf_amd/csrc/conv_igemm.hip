@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
     // The partial rows are indexed by (pixel tile, wave row).  When those fit the 256 rows every (row, filter) has exactly one writer:
     // plain stores, bitwise-reproducible statistics -- and the f32 atomics of the 13x13 stages (each a fabric round trip) were 10 us of
     // a 77 us launch (profiles/r02_igemm_ablation.txt).  Larger layers wrap around the rows and keep the atomic adds.
-    const bool stats_unique = MT * WGM <= Y2_BN_PART_ROWS;
+    const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave row) pair
     auto write_tile = [&](auto checked_tag) {      // interior tiles skip the per-element row test (one VALU compare + branch each)
         constexpr bool CHECKED = decltype(checked_tag)::value;
 #pragma unroll
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(512) void conv3x3_tap_kernel(
     {
         const bool stats = !BNBWD && bn_part != nullptr;
         const bool bstats = BNBWD && bn_part != nullptr;
-        const bool stats_unique = MT * WGM <= Y2_BN_PART_ROWS;
+        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave row) pair
         constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
         static_assert(NW * WROWS * WSTRIDE <= 2 * HBYTES, "tile image fits the halo buffers");
         float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
@@ -1092,16 +1092,30 @@ static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // Y2_BN_PART_ROWS (pixel tile, wave row) pairs get a row each (plain stores, one writer per element); larger grids wrap around
 // R rows with f32 atomic adds, R chosen for <= ~170 adds per address (the 104x104 layer; 20-90 elsewhere) and <= 128 rows to read.
 static thread_local int g_last_stat_rows = Y2_BN_PART_ROWS;
-static int y2_stat_rows(long wave_rows) {
-    if (wave_rows <= Y2_BN_PART_ROWS) return (int)wave_rows;
+// most rows the consumer's prologue accepts for Nf channels (elementwise.hip fin_shape_ok: rows x slice x 8 bytes <= 128 KB), <= 256
+static int y2_stat_rows_limit(int Nf, int vec) {
+    static const int cap = getenv("YOLO2_STAT_ROWS_CAP") ? atoi(getenv("YOLO2_STAT_ROWS_CAP")) : 1;      // A/B: 0 = up to 256 unique rows whatever the consumer reads
+    if (!cap) return Y2_BN_PART_ROWS;
+    int lpr = Nf / vec;
+    if (lpr > 16) lpr = 16;
+    if (lpr < 1) lpr = 1;
+    const long lim = (128L << 10) / ((long)lpr * vec * 8);
+    return lim > Y2_BN_PART_ROWS ? Y2_BN_PART_ROWS : (int)lim;
+}
+static int y2_stat_rows(long wave_rows, int limit) {
+    if (wave_rows <= limit) return (int)wave_rows;         // one row per (pixel tile, wave row): plain stores
     int r = 16;
     while (r < 128 && (long)r * 128 < wave_rows) r <<= 1;
+    while (r > limit) r >>= 1;
     return r;
 }
-static Y2BnBwd y2_with_stat_rows(Y2BnBwd bz, long wave_rows) {
-    const int r = y2_stat_rows(wave_rows);
+// (batch 8, 26x26 stage: 172 unique rows x 512 channels were more than the consumer reads -- those five layers fell back to the
+// separate finalisation launches; they now wrap around 16 rows like the larger grids)
+static Y2BnBwd y2_with_stat_rows(Y2BnBwd bz, long wave_rows, int Nf, int vec) {
+    const int limit = y2_stat_rows_limit(Nf, vec);
+    const int r = y2_stat_rows(wave_rows, limit);
     g_last_stat_rows = r;
-    bz.stat_mask_inv = wave_rows <= Y2_BN_PART_ROWS ? 0 : (Y2_BN_PART_ROWS - 1) ^ (r - 1);
+    bz.stat_mask_inv = wave_rows <= limit ? 0 : (Y2_BN_PART_ROWS - 1) ^ (r - 1);
     return bz;
 }
 extern "C" int yolo2_last_bn_part_rows(void) { return g_last_stat_rows; }
@@ -1111,7 +1125,7 @@ extern "C" int yolo2_last_bn_part_rows(void) { return g_last_stat_rows; }
         const dim3 g_ = (gridv);                                                                                   \
         const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
         for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
-        const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)cdiv(M, BMv) * (NWv / WGNv));                              \
+        const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)cdiv(M, BMv) * (NWv / WGNv), Nf, VEC);                     \
         if (!bz.Y)                                                                                                 \
             conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
                 Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz_);                                     \
@@ -1219,7 +1233,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             (sk_flags = stream_flags()) != nullptr) {
             const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 9, 2, tu.cus, 1};      // "stages" 9: nine taps per halo image
             for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
-            const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4);
+            const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
             static const int k_rotate = getenv("YOLO2_IGEMM_TAP_ROTATE") ? atoi(getenv("YOLO2_IGEMM_TAP_ROTATE")) : 1;       // A/B: 0 = every tile starts at K step 0
 #define Y2T_LAUNCH(BWDv, HRv, NSBv)                                                                                                      \
             conv3x3_tap_kernel<BWDv, HRv, NSBv><<<dim3(tu.cus), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \

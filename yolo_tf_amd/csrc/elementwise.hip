@@ -371,6 +371,11 @@ int y2_colsum_into(const void *Y, int ld, long M, int C, const float *shift, flo
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ld == C);
     int nb = colsum_grid(M, C, vec);
     if (nb > Y2_BN_PART_ROWS) nb = Y2_BN_PART_ROWS;
+    {   // no more rows than a consumer that finalises them in its prologue reads (fin_shape_ok below: rows x slice x 8 bytes <= 128 KB)
+        const int tpr = C / vec, lpr = tpr < 16 ? tpr : 16;
+        const long lim = (128L << 10) / ((long)lpr * vec * 8);
+        if (nb > lim) nb = (int)lim;
+    }
     if (rows_used) *rows_used = nb;
     Y2_DISPATCH_DTYPE(dtype, colsum_kernel<T, 2><<<nb, 256, 0, st>>>((const T *)Y, ld, M, C, part, shift, Y2_BN_PART_ROWS));
     Y2_CHECK_LAUNCH();
