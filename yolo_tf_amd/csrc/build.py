@@ -20,6 +20,8 @@ SOURCES = {
 }
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-unused-result']
 LIB = os.path.join(HERE, 'libyolo2hip.so')
+COMM_LIB = os.path.join(HERE, 'libyolo2comm.so')     # include/yolo2_comm.h: RCCL communicator + bucket all-reduce for C / C++ hosts
+ROCM = os.environ.get('ROCM_PATH', '/opt/rocm')
 
 
 def _stale(out, deps):
@@ -50,7 +52,24 @@ def build(force=False, verbose=True):
         # fails here (not on the GPU box) if any symbol is unresolved.  In a child process: dlopen()ing the library in THIS
         # process before torch is imported would map a second HIP runtime next to torch's bundled one (see _lib.load)
         subprocess.check_call([sys.executable, '-c', 'import ctypes, sys; ctypes.CDLL(sys.argv[1])', LIB])
+    build_comm(force=force, verbose=verbose)
     return LIB
+
+
+def build_comm(force=False, verbose=True):
+    """libyolo2comm.so: host code only (RCCL launches its own kernels).  A separate shared object on purpose: it links /opt/rocm's
+    librccl, and the Python host (torch.distributed, torch's own RCCL) must not map it -- see include/yolo2_comm.h."""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    src = os.path.join(HERE, 'comm.cpp')
+    hdr = os.path.join(HERE, '..', '..', 'include', 'yolo2_comm.h')
+    if force or _stale(COMM_LIB, [src, hdr, os.path.abspath(__file__)]):
+        cmd = [hipcc, '-O2', '-std=c++17', '-fPIC', '-shared', '-o', COMM_LIB, src, '-I' + os.path.join(ROCM, 'include'),
+               '-L' + os.path.join(ROCM, 'lib'), '-lrccl', '-lamdhip64', '-Wl,-rpath,' + os.path.join(ROCM, 'lib')]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        subprocess.check_call([sys.executable, '-c', 'import ctypes, sys; ctypes.CDLL(sys.argv[1])', COMM_LIB])
+    return COMM_LIB
 
 
 if __name__ == '__main__':
