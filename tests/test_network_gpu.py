@@ -819,3 +819,74 @@ def test_no_layer_falls_back_to_separate_finalisation(basedir, B, sizes, monkeyp
         allowed = {'bn_leaky_bwd_apply'} if B * (size // 32) ** 2 < 8 * 13 * 13 else set()
         assert set(calls) <= allowed, (B, size, sorted(set(calls)))
         del calls[:]
+
+
+def _sync_bn_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    from yolo_tf_amd.parallel import init_distributed
+    from yolo_tf_amd.session import TrainSession
+    torch.cuda.set_device(0)
+    init_distributed(backend='gloo')                    # both ranks share the one GPU of the test box: gloo carries the CUDA tensors
+    d = np.load(os.path.join(outdir, 'data.npz'))
+    b, _ = make_builder('darknet', 20, 96, True, os.path.join(outdir, 'base%d' % rank))
+    sess = TrainSession(b, 2, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=3, world_size=world, bucket_mb=8.0, sync_bn=True)
+    e = sess.engine
+    assert e.sync_bn and e.bn_world == 2 and not e.fold_finalize
+    sess.upload_labels([d['l%d' % i][2 * rank:2 * rank + 2] for i in range(6)])
+    images = torch.from_numpy(d['images'][2 * rank:2 * rank + 2]).cuda()
+    sess.step(images)
+    torch.cuda.synchronize()
+    stats = {k: np.asarray(v, np.float32) for k, v in e.get_variables().items() if 'moving_' in k}
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), grads=e.grads.cpu().numpy(), params=e.params.cpu().numpy(), logits=read_t(e, e.output()),
+             loss=np.float64(sess.fetch()['total_loss']), **{'mv/' + k: v for k, v in stats.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_one_process_with_the_joint_batch(tmp_path, basedir):
+    """[mi355x] sync_bn: two ranks x 2 images with batch moments and BN-backward sums exchanged train exactly like ONE process on the four
+    images -- logits, averaged gradients, moving statistics and the updated parameters agree to f32 rounding.
+    (The default -- replica-local statistics -- is what two independent reference processes would compute.)"""
+    import socket
+    import torch.multiprocessing as mp
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    rng = np.random.RandomState(11)
+    images = rng.uniform(0, 255, (4, 96, 96, 3)).astype(np.float32)
+    labels = data.synthetic_batch(4, 20, 3, 3, seed=12)
+    np.savez(str(tmp_path / 'data.npz'), images=images, **{'l%d' % i: np.asarray(l) for i, l in enumerate(labels)})
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_sync_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+    # the single process on the joint batch (two-launch finalisation, like the synchronised run)
+    b, _ = make_builder('darknet', 20, 96, True, basedir)
+    sess = TrainSession(b, 4, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=3)
+    sess.upload_labels(labels)
+    sess.forward_backward(torch.from_numpy(images).cuda())
+    e = sess.engine
+    joint_g = e.grads.cpu().numpy()
+    joint_logits = read_t(e, e.output())
+    joint_loss = sess.fetch()['total_loss']
+    sess.apply_gradients()
+    torch.cuda.synchronize()
+    both_logits = np.concatenate([r0['logits'], r1['logits']])
+    assert rel_l2(both_logits, joint_logits) <= 2e-5, rel_l2(both_logits, joint_logits)
+    assert abs(0.5 * (float(r0['loss']) + float(r1['loss'])) - joint_loss) <= 1e-5 * abs(joint_loss)
+    np.testing.assert_array_equal(r0['grads'], r1['grads'])            # the exchanged (summed) gradient arena
+    g_avg = r0['grads'] / 2.0                                          # sum over ranks of per-rank-mean losses / world == gradient of the joint mean
+    assert rel_l2(g_avg, joint_g) <= 2e-4, rel_l2(g_avg, joint_g)
+    np.testing.assert_array_equal(r0['params'], r1['params'])
+    for k, v in e.get_variables().items():
+        if 'moving_' in k:
+            assert np.abs(r0['mv/' + k] - np.asarray(v, np.float32)).max() <= 1e-6 + 1e-5 * np.abs(r0['mv/' + k]).max(), k
+            np.testing.assert_array_equal(r0['mv/' + k], r1['mv/' + k])
+    # Adam's first step is +-alpha whatever the magnitude: compare the direction of the update instead of its size
+    p_joint = e.params.cpu().numpy()
+    agree = float(np.mean(np.abs(r0['params'] - p_joint) <= 1e-6))     # (a gradient whose sign differs -- |g| at rounding level -- moves by 2 alpha = 2e-3)
+    assert agree >= 0.98, agree

@@ -131,7 +131,8 @@ def main():
     session = TrainSession(builder, args.batch_size, dtype=dtype, optimizer=args.optimizer, learning_rate=args.learning_rate,
                            gradient_clip=args.gradient_clip, config=config, seed=seed, world_size=world,
                            bucket_mb=config.getfloat('mi355x', 'bucket_mb') if config.has_option('mi355x', 'bucket_mb') else 64.0,
-                           grad_dtype=config.get('mi355x', 'grad_dtype') if config.has_option('mi355x', 'grad_dtype') else 'f32')
+                           grad_dtype=config.get('mi355x', 'grad_dtype') if config.has_option('mi355x', 'grad_dtype') else 'f32',
+                           sync_bn=config.getboolean('mi355x', 'sync_bn') if config.has_option('mi355x', 'sync_bn') else False)
     logging.warning('optimizer=%s, dtype=%s, world=%d, parameters=%d' % (args.optimizer, dtype, world, session.engine.n_params))
     # rank 0 alone chooses and reads the checkpoint; the others receive parameters, statistics, optimizer slots and
     # global_step from it (same seed -> same initial weights anyway, but a restore must not depend on what each rank sees)

@@ -28,6 +28,7 @@ LEAKY_ALPHA = 0.1    # model/yolo/function.py:21
 _DTYPES = {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'f32': torch.float32, 'float32': torch.float32}
 
 
+BN_PART_ROWS = 256           # YOLO2_BN_PART_ROWS of include/yolo2_hip.h: rows per plane of a partial-sum buffer
 ARENA_ALIGN = 64      # elements: every variable starts on a 256-byte boundary
 
 
@@ -109,10 +110,16 @@ class _PartPool(object):
 
 
 class Engine(object):
-    def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None):
+    def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None, sync_bn=False):
         if not torch.cuda.is_available():
             raise RuntimeError('yolo_tf_amd.Engine needs an MI355X (no CPU path exists)')
         ops._lib.load()
+        # Synchronised batch normalisation (data-parallel option, [mi355x] sync_bn): batch moments and the BN-backward sums are summed over
+        # the replicas, so N ranks x B images train like one process with N x B images.  The reference is single-device (local statistics
+        # are what N independent replicas of it would compute; that stays the default).  Costs two small collectives per BN layer and
+        # step, and takes the two-launch finalisation forms (the sums have to exist outside a kernel to be exchanged).
+        self.sync_bn = bool(sync_bn) and training
+        self.bn_group, self.bn_world = None, 1        # set by TrainSession once the process group exists
         self.graph = graph
         self.B = int(batch_size)
         self.dtype = _DTYPES[dtype] if isinstance(dtype, str) else dtype
@@ -217,7 +224,7 @@ class Engine(object):
             max_c = max(max_c, ldy)
         self._bindings = {}
         self._tmp_roots = {}
-        self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0'
+        self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0' and not self.sync_bn
         self.pool_ymax = self.fold_finalize and os.environ.get('YOLO2_POOL_YMAX', '1') != '0'
         self._bind(self.graph)
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
@@ -526,10 +533,14 @@ class Engine(object):
                         if self.fold_finalize and ops.bn_fin_supported(rows, op['cout'], self.dtype):
                             fin = (part, rows)              # ... summed by the BN-apply kernel below, in its prologue
                         else:
-                            ops.bn_finalize(self.parts.bufs[part], mmean, M, op['cout'], st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                            if self.sync_bn and self.bn_world > 1:
+                                self._sync_bn_sums(self.parts.bufs[part], op['cout'])
+                            ops.bn_finalize(self.parts.bufs[part], mmean, M * (self.bn_world if self.sync_bn else 1), op['cout'], st['mean'], st['var'],
+                                            mmean, mvar, BN_DECAY)
                             self.parts.consumed(part, cleared=True)
                         mean, var = st['mean'], st['var']
                     elif self.training:
+                        assert not (self.sync_bn and self.bn_world > 1), 'sync_bn needs the statistics from the convolution epilogue (YOLO2_FUSE_BN_STATS=1, dense output)'
                         ops.bn_stats_ema(yb, st['mean'], st['var'], mmean, mvar, BN_DECAY, self.ws, M, op['cout'])
                         mean, var = st['mean'], st['var']
                     else:
@@ -694,10 +705,12 @@ class Engine(object):
                         if own >= 0:
                             self.parts.consumed(own)
                     elif pool is not None:
-                        ops.bn_leaky_pool_bwd_apply(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy,
+                        ag, ab = self._sync_bn_grads(dgam, dbet, cout)
+                        ops.bn_leaky_pool_bwd_apply(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, ag, ab, dy,
                                                     B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA)
                     else:
-                        ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, dgam, dbet, dy, M, cout, BN_EPS, LEAKY_ALPHA)
+                        ag, ab = self._sync_bn_grads(dgam, dbet, cout)
+                        ops.bn_leaky_bwd_apply(gob, ldgo, yb, st['mean'], st['var'], gamma, beta, ag, ab, dy, M, cout, BN_EPS, LEAKY_ALPHA)
                     ring = True
                 elif op['act']:
                     # un-normalised layer + leaky_relu (YOLO v1): dZ from the layer's output sign, then the biased-layer path
@@ -781,6 +794,36 @@ class Engine(object):
         self._phase = 'fwd'
         if side is not None:
             main.wait_stream(side)           # every filter gradient is final before the optimizer / the caller reads them
+
+    def _sync_bn_sums(self, part, C):
+        """Forward, sync_bn: the partial rows [2][256][C] of THIS replica become the sums over ALL replicas (in row 0; bn_finalize then sees
+        world x M samples).  Every replica holds the same shift (the moving mean), so the shifted sums simply add."""
+        import torch.distributed as dist
+        sums = self._bn_sync_buf(2 * C)
+        ops.bn_part_to_grads(part, C, sums[:C], sums[C:])                # column sums of both planes; clears the rows
+        dist.all_reduce(sums, group=self.bn_group)
+        part[:C].copy_(sums[:C])
+        part[BN_PART_ROWS * C:BN_PART_ROWS * C + C].copy_(sums[C:])      # (plane 1 starts BN_PART_ROWS rows after plane 0)
+
+    def _sync_bn_grads(self, dgam, dbet, C):
+        """Backward, sync_bn: the apply pass needs sum(dz * xhat), sum(dz) over ALL replicas' pixels (divided by the global count: passed
+        pre-divided by the world size, the kernel divides by this replica's pixel count).  dgamma / dbeta themselves stay this replica's
+        sums -- the gradient exchange averages them like every other parameter gradient."""
+        if not (self.sync_bn and self.bn_world > 1):
+            return dgam, dbet
+        import torch.distributed as dist
+        sums = self._bn_sync_buf(2 * C)
+        sums[:C].copy_(dgam)
+        sums[C:].copy_(dbet)
+        dist.all_reduce(sums, group=self.bn_group)
+        sums.mul_(1.0 / self.bn_world)
+        return sums[:C], sums[C:]
+
+    def _bn_sync_buf(self, n):
+        buf = getattr(self, '_bn_sync', None)
+        if buf is None or buf.numel() < n:
+            buf = self._bn_sync = torch.zeros(max(n, 4096), dtype=torch.float32, device=self.device)
+        return buf[:n]
 
     def _first_fused(self, op):
         """The image layer (3 channels in an 8-wide pixel, 32 filters, 3x3, batch-normalised, followed only by a 2x2 pool) takes the

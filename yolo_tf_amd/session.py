@@ -23,7 +23,8 @@ class TrainSession(object):
     per-tensor clip -> optimizer; all asynchronous on the current stream."""
 
     def __init__(self, builder, batch_size, dtype='bf16', optimizer='adam', learning_rate=1e-6, gradient_clip=0.0,
-                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None, grad_dtype='f32', comm_cus=None, comm_timing=False):
+                 config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None, grad_dtype='f32', comm_cus=None, comm_timing=False,
+                 sync_bn=False):
         """``sizes``: optional list of (width, height) input sizes for multi-scale training (BASELINE configs[3]); buffers are
         allocated once for the largest, ``set_size`` switches between them, the builder's configured size is selected first."""
         assert builder.training, 'call builder(data, training=True) first'
@@ -39,8 +40,11 @@ class TrainSession(object):
                 traced[wh] = builder.trace(wh[0], wh[1], training=True)
         largest = max(traced, key=lambda wh: wh[0] * wh[1])
         assert all(w <= largest[0] and h <= largest[1] for w, h in traced), 'one size must contain all the others'
-        self.engine = Engine(traced[largest][0], batch_size, dtype, training=True, seed=seed)
+        self.engine = Engine(traced[largest][0], batch_size, dtype, training=True, seed=seed, sync_bn=sync_bn and world_size > 1)
         e = self.engine
+        if e.sync_bn:                # batch moments and BN-backward sums over all replicas ([mi355x] sync_bn; default: replica-local like N reference processes)
+            import torch.distributed as dist
+            e.bn_group, e.bn_world = dist.group.WORLD, int(world_size)
         self.models = {wh: gm[1] for wh, gm in traced.items()}
         m0 = traced[largest][1]
         self.A, self.C = (m0.boxes_per_cell if self.v1 else len(m0.anchors)), m0.classes
