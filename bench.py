@@ -216,6 +216,11 @@ def cpu_nms_baseline(classes):
     return res
 
 
+def _lib_env_overrides():
+    from yolo_tf_amd import _lib
+    return _lib.env_overrides()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -334,7 +339,8 @@ def main():
                                       'BASELINE configs[2]' if (strong and args.names == 80) else 'BASELINE configs[1]' if (args.names == 20 and args.batch == 16) else 'variant'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)',
                        'collective': ('RCCL all-reduce (%s, %s gradients), %d ranks, %d buckets' % (dist.get_backend(), grad_dtype, dist.get_world_size(), len(sess.reducer.buckets)))
-                       if world > 1 else 'none (1 rank)'},
+                       if world > 1 else 'none (1 rank)',
+                       'env_overrides': _lib_env_overrides()},       # YOLO2_* A/B switches in effect ([] = the tested defaults)
             'whole_step_tflops': value * gflop / 1e3,
             'whole_step_frac_of_mfma_peak': value * gflop / 1e3 / peak / world,
             'total_loss': loss['total_loss'],

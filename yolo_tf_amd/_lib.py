@@ -173,7 +173,17 @@ def load():
         fn.restype = _i
         fn.argtypes = args
     _lib = lib
+    over = env_overrides()
+    if over:      # A/B switches select kernel variants: say so once, so that a run that differs from the tested defaults is not silent about it
+        import warnings
+        warnings.warn('YOLO2_* switches set in the environment change kernel selection away from the tested defaults: %s' % ', '.join(over))
     return lib
+
+
+def env_overrides():
+    """The YOLO2_* variables present in the environment (library and engine A/B switches), as 'NAME=value' strings.
+    Everything the parity tests and the driver's benchmark cover is the state in which this list is empty."""
+    return sorted('%s=%s' % (k, v) for k, v in os.environ.items() if k.startswith('YOLO2_'))
 
 
 def query(name, *args):
