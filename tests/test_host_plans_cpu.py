@@ -1,0 +1,101 @@
+"""Host-side planning logic that decides which kernels a training step launches, checked without a GPU: the partial-row buffer pool of
+the engine (who clears what, so that no memset launch is needed), the shapes the folded-finalisation consumers accept, and the
+filter-gradient plans that decide which gradient ranges the step has to clear."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_part_pool_hands_out_clean_buffers_and_has_consumers_clear_the_previous_one():
+    from yolo_tf_amd.engine import _PartPool
+    pool = _PartPool(3, 1024, 'cpu')
+    a = pool.acquire(512)
+    assert pool.busy[a] and pool.dirty[a] == 512
+    pool.bufs[a][:512] = 1.0                                   # the producer's epilogue writes partial rows
+    zbuf, zn = pool.take_to_zero(a)                            # its consumer: nothing else is dirty yet
+    assert zbuf is None and zn == 0
+    pool.consumed(a)                                           # read, not cleared
+    b = pool.acquire(256)
+    assert b != a and float(pool.bufs[b].abs().sum()) == 0.0   # a dirty buffer is never handed to a producer
+    pool.bufs[b][:256] = 2.0
+    zbuf, zn = pool.take_to_zero(b)                            # b's consumer clears a on the side
+    assert zbuf is pool.bufs[a] and zn == 512 and pool.dirty[a] == 0
+    zbuf[:zn] = 0.0                                            # (what grid_zero does inside the consumer kernel)
+    pool.consumed(b)
+    # steady state of a step: every producer finds a clean buffer without the fallback memset
+    for _ in range(50):
+        i = pool.acquire(128)
+        assert float(pool.bufs[i].abs().sum()) == 0.0
+        pool.bufs[i][:128] = 3.0
+        z, n = pool.take_to_zero(i)
+        if z is not None:
+            z[:n] = 0.0
+        pool.consumed(i)
+    # a consumer that clears its own rows (the two-launch finalisation) returns the buffer clean
+    i = pool.acquire(64)
+    pool.bufs[i][:64] = 0.0
+    pool.consumed(i, cleared=True)
+    assert pool.dirty[i] == 0 and not pool.busy[i]
+
+
+def test_part_pool_falls_back_to_a_clear_when_every_buffer_is_dirty():
+    from yolo_tf_amd.engine import _PartPool
+    pool = _PartPool(2, 64, 'cpu')
+    for _ in range(2):
+        i = pool.acquire(64)
+        pool.bufs[i][:] = 5.0
+        pool.consumed(i)                                       # consumed, nobody cleared it
+    i = pool.acquire(32)                                       # (rare path: costs a memset launch on the device)
+    assert float(pool.bufs[i].abs().sum()) == 0.0 and pool.dirty[i] == 32
+
+
+@pytest.fixture(scope='module')
+def q():
+    from yolo_tf_amd import _lib
+    return _lib.query
+
+
+def test_folded_finalisation_shape_rule(q):
+    """rows x (channel slice <= 128 bf16 / 64 f32) x 8 bytes <= 128 KB per workgroup prologue; 16-byte lane groups must divide 256 threads."""
+    F32, BF16 = 0, 1
+    assert q('yolo2_bn_fin_supported', 128, 1024, BF16) == 1 and q('yolo2_bn_fin_supported', 129, 1024, BF16) == 0
+    assert q('yolo2_bn_fin_supported', 256, 64, BF16) == 1 and q('yolo2_bn_fin_supported', 512, 32, BF16) == 1
+    assert q('yolo2_bn_fin_supported', 256, 512, F32) == 1 and q('yolo2_bn_fin_supported', 257, 512, F32) == 0
+    assert q('yolo2_bn_fin_supported', 44, 1024, BF16) == 1                      # batch 8, 13x13 stage
+    assert q('yolo2_bn_fin_supported', 172, 512, BF16) == 0                      # what batch 8 / 26x26 used to leave (producers now wrap to 16 rows)
+    assert q('yolo2_bn_fin_supported', 16, 24, BF16) == 0                        # 3 lane groups do not divide 256
+    assert q('yolo2_bn_fin_supported', 0, 64, BF16) == 0 and q('yolo2_bn_fin_supported', 8, 4, BF16) == 0
+    from yolo_tf_amd import ops
+    assert ops.bn_fin_rows_limit(1024, torch.bfloat16) == 128 and ops.bn_fin_rows_limit(64, torch.bfloat16) == 256
+    assert ops.bn_fin_rows_limit(32, torch.bfloat16) == 512 and ops.bn_fin_rows_limit(24, torch.bfloat16) == 0
+
+
+@pytest.mark.parametrize('batch', [4, 8, 16, 32])
+def test_filter_gradient_plans_decide_which_ranges_the_step_clears(q, batch):
+    """yolo2_conv2d_wgrad_accumulates: layers whose tile grid covers the chip take ONE pixel range and store (their gradient range needs
+    no clearing); the others split the pixels and add atomically into a zeroed range.  The decision depends on the tile count only."""
+    BF16 = 1
+    def acc(H, cin, cout, k):
+        return q('yolo2_conv2d_wgrad_accumulates', batch, H, H, cin, (cin + 7) // 8 * 8, cout, (cout + 7) // 8 * 8, k, BF16)
+    assert acc(13, 512, 1024, 3) == 0 and acc(13, 1024, 1024, 3) == 0 and acc(13, 3072, 1024, 3) == 0      # 288 / 576 / 1728 tiles of 128 x 128
+    assert acc(26, 256, 512, 3) == 1 and acc(52, 128, 256, 3) == 1 and acc(104, 64, 128, 3) == 1 and acc(208, 32, 64, 3) == 1
+    assert acc(13, 1024, 512, 1) == 1 and acc(13, 1024, 125, 1) == 1 and acc(26, 512, 64, 1) == 1
+    assert q('yolo2_conv2d_wgrad_accumulates', 0, 13, 13, 8, 8, 8, 8, 3, BF16) == 1                          # bad arguments: be safe, clear
+
+
+def test_arena_layout_alignment_and_bucket_bounds():
+    """Every variable starts on a 256-byte boundary (a 425-element bias once shifted every later filter off the 128-byte lines) and
+    gradient buckets end on variable boundaries."""
+    from yolo_tf_amd.engine import ARENA_ALIGN
+    from yolo_tf_amd.parallel import make_buckets
+    sizes = [1024 * 425, 425, 3 * 3 * 3072 * 1024, 1024, 1024, 7, 3 * 3 * 32 * 64]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append((off, n))
+        off += (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+    assert all(o % ARENA_ALIGN == 0 for o, _ in offs) and ARENA_ALIGN * 4 == 256
+    buckets = make_buckets(offs, off, (8 << 20) // 4)
+    starts = {o for o, _ in offs} | {off}
+    assert buckets[0][0] == 0 and buckets[-1][1] == off
+    assert all(s in starts and e in starts and e > s for s, e in buckets)
+    assert all(b[1] == n[0] for b, n in zip(buckets, buckets[1:]))
