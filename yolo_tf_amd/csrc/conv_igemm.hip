@@ -41,7 +41,12 @@
 //     bias + leaky ReLU (yolo2_conv2d_bias_leaky, BN-folded inference), and -- for a data gradient whose output is the gradient of a
 //     batch-normalised producer layer -- reduce that layer's dgamma / dbeta sums from the tile image (yolo2_conv2d_dgrad_bn).
 //   * 3x3 layers with >= 1024 input channels on images up to 55 wide take conv3x3_tap_kernel (further down): one halo image per
-//     64-channel chunk serves all nine taps, software-pipelined K loop.
+//     64-channel chunk serves all nine taps, software-pipelined K loop.  Its stream-K tiles walk their 64-channel chunks in a
+//     ROTATED order so that the ~32 workgroups of an XCD read the same bytes of a filter slab (7 MB > the 4 MB L2) at the same
+//     time: 3.6x less fabric traffic on the 3072-channel layer (profiles/r03_l2_stationary_ab.md; the time moved 1.8 %: issue-bound).
+//   * Statistics rows: a producer leaves one partial row per (pixel tile, wave row) while that is no more than the consumer's
+//     prologue reads (y2_stat_rows_limit: 128 rows for >= 128 bf16 channels), else it wraps around 16-128 rows with f32 atomics; the
+//     kernel that consumes the moments finishes them (elementwise.hip *_fin kernels) -- no finalisation launch.
 //   * blockIdx -> tile: filter tile fastest (the blocks of XCD b%8 keep one filter slab in their L2), or,
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"

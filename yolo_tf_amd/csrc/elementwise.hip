@@ -4,6 +4,13 @@
 // All activation traffic is 16-byte vectors (8 bf16 / 4 f32) with lanes running along the
 // contiguous NHWC channel axis; per-channel parameters stay in registers because every thread
 // keeps a fixed channel group while it strides over pixels.
+// Map of the file (the order a training step meets them): image standardisation (image_sums / image_apply: per-workgroup f64 partials
+// folded by the apply kernel); the consumers that FINISH the batch statistics in their own prologue (bn_leaky_fin_kernel: BN apply +
+// leaky, optionally + 2x2 pool, + the raw output at the arg-max for the backward, + the un-pooled activation for a fan-out;
+// bn_bwd_apply_fin_kernel: dgamma / dbeta from partial rows + the BN / leaky / pool backward); their two-launch forms (colsum /
+// reduce_finalize / bn_finalize, bn_leaky(_pool), bn_bwd_reduce / apply) for shapes whose prologue would be too long, for inference and
+// for sync_bn; max pool, reorg, channel moves, bias gradient (one launch for the few rows of a detection head); the optimizers, with
+// Adam fused with the MFMA operand re-layout (adam_filter_prep_kernel); the bf16 wire casts of the data-parallel exchange.
 #include "common.h"
 #include <stdlib.h>
 #include <stdarg.h>
