@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-TAP_ON = os.environ.get('YOLO2_IGEMM_TAP', '1') != '0'      # (A/B switch: the per-tap 256x128 stream-K kernel takes these layers when off)
+TAP_STAGES = {'0': 3, '1': 9, '2': 18}[os.environ.get('YOLO2_IGEMM_TAP', '2')]      # plan word 'stages' of the kernel that takes the 13x13 layers: ping-pong tap-fused (default), round-2 tap-fused, per-tap stream-K
 
 from oracle import yolo2_ref as R
 
@@ -119,9 +119,9 @@ def test_forward_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
         assert float(part.abs().max()) == 0.0
     if name in ('conv18_19', 'conv20') and B == 16:
         # the launches that carry the benchmark: tap-fused 256x128 stream-K, one workgroup per CU ('stages' 9 = nine taps per halo image)
-        assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8 and (plan['stages'] == 9) == TAP_ON, plan
+        assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8 and plan['stages'] == TAP_STAGES, plan
     if name == 'conv13_15_17' and B == 16:
-        assert plan['split'] == 2 and plan['BM'] == 128, plan      # 176 tiles for 256 CUs: stream-K on the 128x128 tile
+        assert plan['split'] == 2 and (plan['BM'], plan['stages']) == ((256, 18) if TAP_STAGES == 18 else (128, 3)), plan      # 88 / 176 tiles for 256 CUs: stream-K
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', [c for c in _cases() if c.values[2] != 'conv0'])
@@ -141,7 +141,7 @@ def test_dgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     assert np.all(got[..., cin:] == 0)
     check_act(got[..., :cin], R.conv2d_dgrad(dy, w), 'dgrad %s %s' % (cname, name))
     if name in ('conv18_19', 'conv20') and B == 16:
-        assert plan['BM'] == 256 and plan['split'] == 2 and (plan['stages'] == 9) == TAP_ON, plan
+        assert plan['BM'] == 256 and plan['split'] == 2 and plan['stages'] == TAP_STAGES, plan
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', list(_cases()))

@@ -201,15 +201,21 @@ def _bn_bwd_sums_oracle(dA, yprev, mean, var, gamma, beta, eps, alpha=0.1):
 
 
 TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 256), (8, 13, 13, 1024, 504), (16, 26, 26, 256, 136),
-              (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256)]
+              (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256),
+              (3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
+# variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong DMA position)
+TAP_VARIANTS = {'tap': (1, 0, 0), 'pp': (2, 1, 0), 'pp_tiles': (2, 2, 0), 'pp_dma1': (2, 1, 1)}
 
 
 @pytest.mark.parametrize('epilogue', ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn'])
+@pytest.mark.parametrize('variant', list(TAP_VARIANTS))
 @pytest.mark.parametrize('shape', TAP_SHAPES)
-def test_conv_tap_fused_3x3(ops, shape, epilogue):
-    """conv3x3_tap_kernel (one halo image per 64-channel chunk, nine taps read from it) against the per-tap kernel on the same
-    operands -- same products, a different f32 summation order across stream-K segments only -- and against the oracle."""
+def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
+    """The tap-fused 3x3 kernels (one halo image per 64-channel chunk, nine taps read from it: conv3x3_tap_kernel of round 2 and the
+    ping-pong conv3x3_pp_kernel, as stream-K and with one workgroup per tile) against the per-tap kernel on the same operands -- same
+    products, a different f32 summation order across stream-K segments only -- and against the oracle."""
     B, H, W, Cin, Cout = shape
+    mode, pp_grid, pp_dma = TAP_VARIANTS[variant]
     k, M = 3, B * H * W
     rng = np.random.RandomState(sum(shape) + 3)
     x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
@@ -223,7 +229,8 @@ def test_conv_tap_fused_3x3(ops, shape, epilogue):
     bias = dev(rng.randn(Cout).astype(np.float32))
     out = {}
     for tap in (0, 1):
-        ops.set_igemm_tap(tap)     # (run with YOLO2_IGEMM_TAP_MIN_STEPS=0 YOLO2_IGEMM_TAP_MIN_SHARE=12 to force the short reductions through it too)
+        ops.set_igemm_tap(mode if tap else 0)     # (the round-2 kernel: run with YOLO2_IGEMM_TAP_MIN_STEPS=0 YOLO2_IGEMM_TAP_MIN_SHARE=12 to force the short reductions through it too)
+        ops.set_pp(grid=pp_grid, dmapos=pp_dma, min_steps=0, min_share=0)      # every shape of this test takes the ping-pong kernel
         try:
             O = torch.zeros(M * ldo, dtype=T, device='cuda')
             extra = None
@@ -257,12 +264,18 @@ def test_conv_tap_fused_3x3(ops, shape, epilogue):
                 extra = (dg, db, part, None, yprev, pm, pv, pg, pb)
             plan = ops.last_conv_plan()
             torch.cuda.synchronize()
-            takes_tap = tap and (9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_STEPS', 144))
-                                 and -(-M // 256) * -(-Cout // 128) * 9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_SHARE', 40)) * 256)
-            assert (plan['stages'] == 9) == bool(takes_tap), plan
+            if mode == 1:
+                takes_tap = tap and (9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_STEPS', 144))
+                                     and -(-M // 256) * -(-Cout // 128) * 9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_SHARE', 40)) * 256)
+                assert (plan['stages'] == 9) == bool(takes_tap), plan
+            else:
+                assert (plan['stages'] == 18) == bool(tap and Cout > 64), plan
+                if tap and pp_grid == 2:
+                    assert plan['grid_x'] == -(-M // 256) * -(-Cout // 128), plan
             out[tap] = (host(O).reshape(M, ldo), plan, extra)
         finally:
-            ops.set_igemm_tap(1)
+            ops.set_igemm_tap(2)
+            ops.set_pp(grid=0, dmapos=0, min_steps=18, min_share=12)
     y0, y1 = out[0][0], out[1][0]
     assert np.all(y1[:, Cout:] == 0)
     assert_close(y1, y0, 8e-3, 'tap-fused vs per-tap %s %s' % (shape, epilogue))     # one bf16 ulp where the f32 sums round differently

@@ -10,6 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     'conv_igemm.hip': [],
+    'conv_pp.hip': [],
     'conv_wgrad.hip': [],
     'conv_first.hip': [],
     'elementwise.hip': [],
@@ -33,7 +34,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    headers = [os.path.join(HERE, 'common.h'), os.path.join(HERE, '..', '..', 'include', 'yolo2_hip.h'), os.path.abspath(__file__)]
+    headers = [os.path.join(HERE, 'common.h'), os.path.join(HERE, 'conv_shared.h'), os.path.join(HERE, '..', '..', 'include', 'yolo2_hip.h'), os.path.abspath(__file__)]
     objs = []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)

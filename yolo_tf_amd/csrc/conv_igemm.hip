@@ -50,6 +50,7 @@
 //   * blockIdx -> tile: filter tile fastest (the blocks of XCD b%8 keep one filter slab in their L2), or,
 //     when the filter operand is small, one contiguous run of M tiles per XCD (halo rows shared in L2).
 #include "common.h"
+#include "conv_shared.h"
 #include <stdlib.h>
 #include <atomic>
 #include <mutex>
@@ -74,23 +75,6 @@ template <> struct Mma<float> {
 // (Timing-ablation hooks -- no epilogue / no MFMA / no fragment reads / no DMA builds -- live in scripts/experiments/conv_igemm_ablation_hooks.patch,
 // applied to a COPY of this file by scripts/abl_build.sh; the product source carries none.)
 #define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
-#define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
-
-// Data-gradient launches whose output IS the gradient dA of a batch-normalised producer layer (a = leaky(bn(y))) can reduce that
-// layer's BN + leaky backward sums in their epilogue: Y non-NULL selects it.  Per output element dz = dA * leaky'(z),
-// xhat = (y - mean) * rstd; the tile adds its columns' sum(dz * xhat) [plane 0] and sum(dz) [plane 1] to the partial rows the
-// forward statistics use.  Replaces one full read of dA and y (bn_bwd_reduce_kernel) per layer with a read of y alone, issued while
-// the tile is still in LDS.
-struct Y2BnBwd {
-    const void *Y;      // pre-normalisation output of the producer layer, [M][Nf] (pixel stride = Nf)
-    const float *mean, *var, *gamma, *beta;
-    float eps, alpha;
-    // bits cleared from the partial-row index mask (Y2_BN_PART_ROWS - 1): grids with more (pixel tile, wave row) pairs than rows wrap
-    // around R = 256 >> popcount(stat_mask_inv) rows, chosen by the host so that the consumer that finalises the rows in its prologue
-    // (yolo2_bn_leaky_fin & co.) reads few of them while same-address atomic adds stay rare (y2_stat_rows below).  0 = all 256 rows.
-    int stat_mask_inv;
-};
-
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
 // CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
 template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int CH = 4, int NW = 4, int BMv = 128, bool BNBWD = false>
@@ -1171,9 +1155,23 @@ static constexpr bool igemm_wide_fits() {
 
 // tap-fused 3x3 variant on/off (default: env YOLO2_IGEMM_TAP, else on); yolo2_debug_set_igemm_tap flips it at run time so that
 // tests can compare both variants on the same inputs
-static std::atomic<int> g_igemm_tap{getenv("YOLO2_IGEMM_TAP") ? atoi(getenv("YOLO2_IGEMM_TAP")) : 1};
-extern "C" int yolo2_debug_set_igemm_tap(int on) {
-    g_igemm_tap.store(on ? 1 : 0, std::memory_order_relaxed);
+// 0 = per-tap kernels only, 1 = round-2 tap-fused kernel (conv3x3_tap_kernel), 2 = ping-pong tap-fused kernel (conv_pp.hip; default)
+static std::atomic<int> g_igemm_tap{getenv("YOLO2_IGEMM_TAP") ? atoi(getenv("YOLO2_IGEMM_TAP")) : 2};
+extern "C" int yolo2_debug_set_igemm_tap(int mode) {
+    g_igemm_tap.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+    return YOLO2_OK;
+}
+// ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
+// dmapos 0/1 = DMA pieces at the head of the LOAD phase / inside the MFMA phase; min_steps, min_share = the launch gates below (< 0: keep)
+static std::atomic<int> g_pp_grid{getenv("YOLO2_PP_GRID") ? atoi(getenv("YOLO2_PP_GRID")) : 0};
+static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_DMAPOS") ? atoi(getenv("YOLO2_PP_DMAPOS")) : 0};
+static std::atomic<long> g_pp_min_steps{getenv("YOLO2_PP_MIN_STEPS") ? atol(getenv("YOLO2_PP_MIN_STEPS")) : 18};
+static std::atomic<long> g_pp_min_share{getenv("YOLO2_PP_MIN_SHARE") ? atol(getenv("YOLO2_PP_MIN_SHARE")) : 12};
+extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
+    if (grid >= 0) g_pp_grid.store(grid, std::memory_order_relaxed);
+    if (dmapos >= 0) g_pp_dmapos.store(dmapos ? 1 : 0, std::memory_order_relaxed);
+    if (min_steps >= 0) g_pp_min_steps.store(min_steps, std::memory_order_relaxed);
+    if (min_share >= 0) g_pp_min_share.store(min_share, std::memory_order_relaxed);
     return YOLO2_OK;
 }
 
@@ -1227,7 +1225,31 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     // 3x3 layers on images up to 55 pixels wide (the 52x52, 26x26 and 13x13 stages): tap-fused kernel, one halo image per 64-channel
     // chunk instead of nine shifted pixel tiles (conv3x3_tap_kernel above), always stream-K over one workgroup per CU
     if constexpr (std::is_same<T, bf16>::value) {
-        const int tap_on = g_igemm_tap.load(std::memory_order_relaxed);
+        const int tap_mode = g_igemm_tap.load(std::memory_order_relaxed);
+        const int tap_on = tap_mode == 1;
+        // Ping-pong tap-fused kernel (conv_pp.hip): every 3x3 layer on images up to 55 wide whose input is a multiple of 64 channels.
+        // Stream-K over one workgroup per CU when a workgroup's share of the flat (tile, K step) space amortises its hand-offs;
+        // one workgroup per tile otherwise.
+        if (tap_mode == 2 && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream &&
+            (long)9 * (Cp / 64) >= g_pp_min_steps.load(std::memory_order_relaxed) && tu.cus <= Y2_STREAM_FLAG_WORDS) {
+            const long tiles_t = (long)MT2 * NT2, units_p = tiles_t * 9 * (Cp / 64);
+            const int gm = g_pp_grid.load(std::memory_order_relaxed);
+            const bool can_stream = (size_t)tu.cus * Y2T_BM * Y2T_BN * sizeof(float) <= ws_bytes;
+            int grid = 0;
+            if (gm == 1) grid = can_stream ? tu.cus : 0;
+            else if (gm == 2) grid = tiles_t <= Y2_STREAM_FLAG_WORDS ? (int)tiles_t : 0;
+            else if (can_stream && units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus) grid = tu.cus;
+            else if (tiles_t >= tu.cus / 2 && tiles_t <= Y2_STREAM_FLAG_WORDS) grid = (int)tiles_t;
+            if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
+                const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
+                for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
+                const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
+                static const int k_rotate_pp = getenv("YOLO2_IGEMM_TAP_ROTATE") ? atoi(getenv("YOLO2_IGEMM_TAP_ROTATE")) : 1;
+                if (y2_conv3x3_pp_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_,
+                                         k_rotate_pp, grid, g_pp_dmapos.load(std::memory_order_relaxed), st) == 0)
+                    return 0;
+            }
+        }
         // (measured, profiles/r02_igemm_tap.md: pays on the long reductions -- >= 1024 input channels; shorter ones keep the per-tap kernels)
         static const long tap_min_steps = getenv("YOLO2_IGEMM_TAP_MIN_STEPS") ? atol(getenv("YOLO2_IGEMM_TAP_MIN_STEPS")) : 144;
         // ... and when a workgroup's share is long enough to amortise the halo prologue of its (up to three) segments

@@ -1,0 +1,467 @@
+// Ping-pong tap-fused 3x3 implicit GEMM (bf16, 256 x 128 tile, 8 waves of 64 x 64), forward and data gradient.  Round 4.
+//
+// Replaces slim.layers.conv2d for the 3x3 layers with >= 64-channel-multiple inputs on images up to 55 wide (reference
+// model/yolo2/inference.py:81-117) and its tf.gradients input gradient (train.py:127-129).  Same operand layouts, halo image, stream-K
+// decomposition and epilogues as conv3x3_tap_kernel (conv_igemm.hip); what changes is WHO does WHAT WHEN inside a K step.
+//
+// What the counters said about the round-2 kernel (profiles/r02_igemm_tap.md, r02_final_sq_counters.md): a K step (one tap of one
+// 64-channel chunk: 16 MFMAs, 16 ds_read_b128 and 3 DMA pieces per wave) took 0.95 us, of which the 32 MFMAs of a SIMD are 0.45 us
+// and the instruction skeleton around them 0.52 us -- the two simply ADD UP, because every barrier puts all eight waves in the same
+// phase: both waves of a SIMD compete for the matrix pipe together and then idle it together.  Here the two waves of a SIMD are kept in
+// OPPOSITE phases by construction (the 8-wave attention schedule of MI355X_MICROARCH.md "Two waves per SIMD"):
+//
+//     waves 0-3 (one per SIMD)   LOAD(s) | MFMA(s) | LOAD(s+1) | MFMA(s+1) | ...
+//     waves 4-7 (one per SIMD)           | LOAD(s) | MFMA(s)   | LOAD(s+1) | MFMA(s+1) ...        ("|" = s_barrier of the whole workgroup)
+//
+//   LOAD(s): the step's 3 DMA pieces (NSB-1 steps ahead), its 16 fragment reads into ONE register set, counted vmcnt, lgkmcnt(0).
+//   MFMA(s): sixteen back-to-back MFMAs on registers only.  The matrix pipe of a SIMD always has exactly one owner; the partner's LDS
+//   latency, DMA issue and address arithmetic run beside it.  The second group starts one barrier late and the first group pads one
+//   barrier at the end of a segment, so both execute the same number of barriers.
+//   Hazards (s = K step, slot = s mod NSB of the filter ring, D = NSB-1 = DMA distance):
+//     RAW  a wave's pieces of step s+1 are waited for (counted vmcnt) at the end of its LOAD(s), i.e. at least one barrier before
+//          the first group reads them in LOAD(s+1);
+//     WAR  the DMA of step s+D lands in the slot of step s-1, whose last reader (second group, LOAD(s-1)) retired its reads with
+//          lgkmcnt(0) one barrier before the first group issues that DMA in LOAD(s).
+//   * The nine taps are unrolled: tap offsets, swizzle terms and image-border masks become 18 precomputed LDS addresses per lane
+//     (one per tap and fragment row; masked (pixel, tap) pairs point at a zero KiB inside each halo buffer, so switching halo buffers is
+//     one add per address) -- the ~46 VALU + ~60 SALU of per-step addressing of the round-2 kernel shrink to ~14 VALU.
+//   * One fragment register set (64 VGPRs) instead of two: ~170 VGPRs.
+#include "common.h"
+#include "conv_shared.h"
+#include <type_traits>
+
+#define Y2P_BM 256
+#define Y2P_BN 128
+#define Y2P_BBYTES (Y2P_BN * 128)
+#define Y2P_LOADS 3                        // DMA instructions per wave per K step: 1 halo slot + 2 filter pieces
+
+// HROWS = halo rows held (>= 256 + 2 W + 2, multiple of 8), NSB = filter ring depth (DMA runs NSB-1 steps ahead of the reads),
+// DMAPOS: 0 = a step's DMA pieces are issued at the head of its LOAD phase, 1 = behind the first four MFMAs of its MFMA phase
+template <bool BNBWD, int HROWS, int NSB, int DMAPOS>
+__global__ __launch_bounds__(512) void conv3x3_pp_kernel(
+    const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
+    bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate) {
+    typedef bf16 T;
+    constexpr int BM = Y2P_BM, BN = Y2P_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
+    constexpr int HBYTES = HROWS * 128, HB = HBYTES + 1024, RING = 2 * HB, D = NSB - 1;
+    constexpr int HPIECES = HROWS / 8, HSLOTS = (HPIECES + NW - 1) / NW;
+    // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
+    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + 1 - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + NSB * Y2P_BBYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int MT = (M + BM - 1) / BM;
+    const int nk = (Cp / 64) * TAPS;                     // K steps per tile: (64-channel chunk, tap)
+    const long su_total = (long)MT * NT * nk;
+    const int G = gridDim.x;
+    const int wx = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+    long su = wx * su_total / G;
+    const long su_end = (wx + 1) * su_total / G;
+    // K rotation of the stream-K tiles (conv3x3_tap_kernel; profiles/r03_l2_stationary_ab.md): chunk c of tile t lives at memory chunk (c + rot_t) mod nch
+    const int nch = Cp / 64;
+    const double share = (double)su_total / (double)G;
+    const int shares_per_tile = (int)((double)nk / share + 0.5);
+    const double drift_chunks = k_rotate && shares_per_tile >= 2 ? ((double)shares_per_tile * share - (double)nk) / (double)TAPS : 0.0;
+
+    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
+    const double rcp_hw = 1.0 / (double)(H * W);
+    const float rcp_w = 1.0f / (float)W;
+    const int frow = lane & 31;
+    unsigned char *const zero0 = smem + HBYTES;         // the zero KiB of halo buffer 0: also the sink of idle DMA slots (out-of-range DMA writes zeros)
+    typedef __attribute__((address_space(3))) void *lds_void_ptr;
+    typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
+
+  for (bool first_seg = true;; first_seg = false) {
+    if (su >= su_end) break;
+    const int t = (int)(su / nk);
+    const int kt_beg = (int)(su - (long)t * nk);
+    const int kt_end = (int)min((long)nk, kt_beg + (su_end - su));
+    su += kt_end - kt_beg;
+    const int nt = t / MT, mt = t - nt * MT;
+    if (!first_seg) __syncthreads();                     // every wave is done with the previous segment's LDS (tile image of its epilogue included)
+    const int m0 = mt * BM, n0 = nt * BN;
+    int rot;                                             // this tile's chunk rotation, 0 <= rot < nch
+    {
+        const long r = (long)__builtin_floor(-(double)t * drift_chunks + 0.5);
+        rot = (int)(r % nch);
+        if (rot < 0) rot += nch;
+        rot = __builtin_amdgcn_readfirstlane(rot);
+    }
+    auto mem_chunk = [&](int c) { const int m = c + rot; return m >= nch ? m - nch : m; };      // logical chunk (0 <= c <= nch) -> chunk in memory
+
+    // both zero KiB (the previous segment's epilogue staged its tile image over them)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)zero0, 16, Y2_OOB, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)(zero0 + HB), 16, Y2_OOB, 0, 0, 0);
+
+    // halo DMA descriptor: slot j of this wave is piece j * 8 + wave = halo rows 8 * piece .. + 7.  Rows before pixel 0 wrap to offsets
+    // >= 2^31 and rows past the last pixel lie beyond num_records: both read as zeros.  Source-side swizzle ((row >> 1) & 7).
+    const int hr0 = wave * 8 + (lane >> 3);
+    const unsigned h_voff0 = (unsigned)(m0 - (W + 1) + hr0) * (unsigned)ldp * 2u + (unsigned)(((lane & 7) ^ ((hr0 >> 1) & 7)) * 16);
+    const unsigned h_stride = 64u * (unsigned)ldp * 2u;
+    // filter DMA descriptor (two pieces per wave: rows r and r + 8; filters >= Nf lie beyond num_records)
+    const int br0 = wave * 16 + (lane >> 3);
+    unsigned b_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = br0 + 8 * i;
+        b_voff[i] = (unsigned)(n0 + r) * (unsigned)(TAPS * Cp) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    }
+    // which of the nine taps of this lane's two fragment rows lie inside the image
+    unsigned amask = 0;                                  // 9 bits per fragment row, row i at bit 16 * i
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + frow;
+        unsigned mask = 0;
+        if (m < M) {
+            const int HW = H * W;
+            int bq = (int)((double)m * rcp_hw);
+            int rem = m - bq * HW;
+            if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
+            int h = (int)((float)rem * rcp_w);
+            int w = rem - h * W;
+            if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
+            const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+            mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
+        }
+        amask |= mask << (16 * i);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- LDS read addresses.  A: one per (tap, fragment row), valid for the halo buffer of the current chunk parity; the 16-k group
+    // kk is XORed in (bits 5-6 come from the swizzle term alone: every other summand is a multiple of 128).  B: one per 16-k group.
+    const unsigned lds0 = y2_lds_addr(smem);
+    const unsigned hi16 = (unsigned)(lane >> 5) << 4;
+    const int c_first = kt_beg / TAPS;
+    unsigned aaddr[TAPS][TM];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+        const int dh = tp / 3 - 1, dw = tp % 3 - 1;
+        const unsigned toffb = (unsigned)(((W + 1) + dh * W + dw) * ROWB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned hb = (unsigned)((wm * (TM * 32) + i * 32 + frow) * ROWB) + toffb;      // halo row * 128
+            const bool ok = ((amask >> (16 * i + tp)) & 1u) != 0u;
+            const unsigned sw = ((hb >> 4) & 0x70u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane's half of the k group
+            // masked (pixel, tap): the buffer's zero KiB, at the same offset inside a 256-byte bank line as the real row
+            aaddr[tp][i] = lds0 + (unsigned)((c_first & 1) * HB) + (ok ? hb : (unsigned)HBYTES + (hb & 0x80u)) + sw;
+        }
+    }
+    unsigned baddr[4];
+    {
+        const unsigned brow = lds0 + (unsigned)(RING + (wn * TN * 32 + frow) * ROWB);
+        const unsigned bx = hi16 ^ ((unsigned)((frow >> 1) & 7) << 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) baddr[kk] = brow + (bx ^ (unsigned)(kk * 32));
+    }
+
+    // one DMA slot: halo piece `hs` of chunk `hc` (or an idle write into the zero KiB) + the filter tile of K step `kb` into ring stage `bstage`
+    auto issue_slot = [&](int hs, int hc, int hc_mem, bool hreal, int kb, unsigned offB, int bstage) {
+        {
+            const bool real = hreal && hs * NW + wave < HPIECES;
+            unsigned char *dst = real ? smem + (hc & 1) * HB + (hs * NW + wave) * 1024 : zero0;
+            const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)hc_mem * 128u : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
+        }
+        const bool breal = kb < kt_end;
+        unsigned char *Bs = smem + RING + bstage * Y2P_BBYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char *dst = Bs + (wave * 2 + i) * 1024;             // (an idle slot zero-fills a stage no valid step reads any more)
+            const unsigned voff = breal ? b_voff[i] + offB : Y2_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
+        }
+    };
+    auto filt_off = [&](int kb) {                        // byte offset of K step kb inside a filter row (run-time form: prologue only)
+        const int bc = kb / TAPS, bt = kb - bc * TAPS;
+        return (unsigned)(mem_chunk(bc) * TAPS * 64 + bt * 64) * 2u;
+    };
+
+    {   // prologue: the whole halo of the first chunk (+ the pieces of the next chunk whose slots this segment starts behind),
+        // then the filter tiles of steps kt_beg .. kt_beg + D - 1 into ring stages 0 .. D-1
+        const int c_tap = kt_beg - c_first * TAPS;
+#pragma unroll
+        for (int j = 0; j < HSLOTS; ++j) {
+            const bool real = j * NW + wave < HPIECES;
+            unsigned char *dst = real ? smem + (c_first & 1) * HB + (j * NW + wave) * 1024 : zero0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_first) * 128u : Y2_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < HSLOTS; ++j) {           // slots 0 .. c_tap-1 of the NEXT chunk's halo would have been issued by now
+            const bool real = j < c_tap && j * NW + wave < HPIECES && (c_first + 1) * TAPS < kt_end;
+            unsigned char *dst = real ? smem + ((c_first + 1) & 1) * HB + (j * NW + wave) * 1024 : zero0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_first + 1) * 128u : Y2_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue_slot(0, 0, 0, false, kt_beg + d, filt_off(kt_beg + d), d);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
+    __builtin_amdgcn_sched_barrier(0);
+
+    bf16x8 fa[4][TM], fb[4][TN];
+    int kt = kt_beg;                                     // the K step the next executed phase pair belongs to
+    int stage_r = 0, stage_i = D;                        // ring stage read by step kt / filled by the DMA slot of step kt (= stage of step kt + D)
+
+    for (int c = c_first; c * TAPS < kt_end; ++c) {
+        const int lo = max(0, kt_beg - c * TAPS), hi = min(TAPS, kt_end - c * TAPS);       // taps of this chunk inside the segment
+        const int mc0 = mem_chunk(c), mc1 = mem_chunk(c + 1);
+        const bool next_ok = (c + 1) * TAPS < kt_end;
+        const unsigned delta = (c & 1) ? (unsigned)(-HB) : (unsigned)HB;                   // to the other halo buffer
+        auto step = [&](auto tap_tag) {
+            constexpr int tp = decltype(tap_tag)::value;
+            if (tp >= lo && tp < hi) {
+                constexpr int bt = (tp + D) % TAPS;
+                const unsigned offB = (unsigned)(((tp + D >= TAPS) ? mc1 : mc0) * TAPS * 64 + bt * 64) * 2u;
+                auto dma = [&]() { issue_slot(tp, c + 1, mc1, tp < HSLOTS && next_ok, kt + D, offB, stage_i); };
+                // ---- LOAD phase
+                if (DMAPOS == 0) dma();
+                const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
+                    const unsigned bb = baddr[kk] + so;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's pieces of step kt+1 have landed (the D-1 newest slots -- D-2 when this step's slot is issued later -- stay in flight)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMAPOS == 0 ? D - 1 : D - 2) * Y2P_LOADS) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA phase: registers only
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    if (DMAPOS == 1 && kk == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dma();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                ++kt;
+                stage_r = stage_r == NSB - 1 ? 0 : stage_r + 1;
+                stage_i = stage_i == NSB - 1 ? 0 : stage_i + 1;
+            }
+            // the next chunk reads the other halo buffer (every tap's addresses move, whether or not this segment ran the tap)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) aaddr[tp][i] += delta;
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- stream-K hand-off (as in conv_igemm_kernel: the workgroup holding K step 0 of a tile owns it; a tail segment is parked)
+    {
+        constexpr int SLOT = BM * BN;
+        const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
+        const unsigned slot_lane = (unsigned)(((size_t)wave * (TM * TN * 16 * 64) + (size_t)lane * 4) * sizeof(float));
+        if (kt_beg > 0) {
+            const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcS, mine + ((i * TN + j) * 4 + q4) * 1024, 0, 16);
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        if (kt_end < nk) {
+            const long tile_end = su - kt_end + nk;
+            long covered = su;
+            for (int p = wx + 1; covered < tile_end; ++p) {
+                if (tid == 0) {
+                    while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
+                    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, theirs + ((i * TN + j) * 4 + q4) * 1024, 0, 16));
+                            acc[i][j][4 * q4] += v[0];
+                            acc[i][j][4 * q4 + 1] += v[1];
+                            acc[i][j][4 * q4 + 2] += v[2];
+                            acc[i][j][4 * q4 + 3] += v[3];
+                        }
+                covered = (long)(p + 1) * su_total / G;
+            }
+        }
+    }
+
+    // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave LDS image, 16-byte stores), with the
+    // forward statistics or the producer layer's BN-backward sums taken from the rounded values
+    {
+        const bool stats = !BNBWD && bn_part != nullptr;
+        const bool bstats = BNBWD && bn_part != nullptr;
+        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave row) pair
+        constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
+        static_assert(NW * WROWS * WSTRIDE <= RING, "tile image fits the halo buffers");
+        float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
+        Vec16<T> yv[YG];
+        const int bz_nb = min(n0 + wn * TN * 32 + (lane % WCPR) * VEC, Nf - VEC);
+        auto bz_load_y = [&](int it0) {
+#pragma unroll
+            for (int u = 0; u < YG; ++u) {
+                const int m = min(m0 + wm * WROWS + ((it0 + u) * 64 + lane) / WCPR, M - 1);
+                yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write zeros into ring stages / the zero KiB)
+        __syncthreads();                                      // every wave has finished reading the last step's operands
+        unsigned char *wreg = smem + wave * (WROWS * WSTRIDE);
+        const bool tail = m0 + BM > M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const bool n_ok = n < Nf;
+            const float bv = (bias && n_ok) ? bias[n] : 0.f;
+            const float sh = (stats && n_ok) ? bn_shift[n] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r] + bv;
+                    if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
+                    const T o = (T)v;
+                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane & 31)) * 2) = o;
+                    if (stats && (!tail || m0 + wm * WROWS + row < M)) {
+                        const float d = (float)o - sh;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                }
+            }
+            if (stats) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lane < 32 && n_ok) {
+                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                    float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
+                    if (stats_unique) { *p1 = s1; *p2 = s2; }
+                    else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
+                }
+            }
+        }
+        if (bstats) {
+            bz_load_y(0);
+#pragma unroll
+            for (int k = 0; k < VEC; k += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + bz_nb + k), b = *reinterpret_cast<const f32x4 *>(bz.var + bz_nb + k);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + bz_nb + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + bz_nb + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cmu[k + q] = a[q];
+                    cinv[k + q] = 1.0f / sqrtf(b[q] + bz.eps);
+                    cga[k + q] = c[q];
+                    cbt[k + q] = d[q];
+                    ps[0][k + q] = ps[1][k + q] = 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = it * 64 + lane;
+            const int row = id / WCPR, ch = id % WCPR;
+            const int m = m0 + wm * WROWS + row;
+            const int n = n0 + wn * TN * 32 + ch * VEC;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
+            if (bstats && it && it % YG == 0) bz_load_y(it);
+            if (m < M && n < Nf) {
+                *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+                if (bstats) {
+                    const Vec16<T> y = yv[it % YG];
+                    Vec16<T> d;
+                    d.v = __builtin_bit_cast(decltype(d.v), v);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        const float xh = (y.get(k) - cmu[k]) * cinv[k];
+                        const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
+                        const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
+                        ps[0][k] += g * xh;
+                        ps[1][k] += g;
+                    }
+                }
+            }
+        }
+        if (bstats) {
+#pragma unroll
+            for (int off = WCPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    ps[0][k] += __shfl_xor(ps[0][k], off, 64);
+                    ps[1][k] += __shfl_xor(ps[1][k], off, 64);
+                }
+            const int nb = n0 + wn * TN * 32 + lane * VEC;
+            if (lane < WCPR && nb < Nf) {
+                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (stats_unique) { p1[k] = ps[0][k]; p2[k] = ps[1][k]; }
+                    else { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
+                }
+            }
+        }
+    }
+  }
+}
+
+// Launch (called by conv_igemm.hip launch_conv once it has decided that the shape takes this kernel): `grid` workgroups share the
+// flat (tile, K step) space -- one per CU = stream-K; one per tile = whole tiles, no hand-off.
+int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
+                         int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
+                         const Y2BnBwd &bz, int k_rotate, int grid, int dmapos, hipStream_t st) {
+#define Y2P_LAUNCH(BWDv, HRv, NSBv, DPv)                                                                                                    \
+    conv3x3_pp_kernel<BWDv, HRv, NSBv, DPv><<<dim3(grid), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
+                                                                        H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate)
+#define Y2P_LAUNCH_DP(BWDv, HRv, NSBv) do { if (dmapos) Y2P_LAUNCH(BWDv, HRv, NSBv, 1); else Y2P_LAUNCH(BWDv, HRv, NSBv, 0); } while (0)
+    if (W <= 27) { if (bz.Y) Y2P_LAUNCH_DP(true, 312, 5); else Y2P_LAUNCH_DP(false, 312, 5); }
+    else if (W <= 55) { if (bz.Y) Y2P_LAUNCH_DP(true, 368, 4); else Y2P_LAUNCH_DP(false, 368, 4); }
+    else return 1;
+#undef Y2P_LAUNCH_DP
+#undef Y2P_LAUNCH
+    return 0;
+}

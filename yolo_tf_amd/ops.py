@@ -336,9 +336,14 @@ def noop():
     call('yolo2_debug_noop', _stream())
 
 
-def set_igemm_tap(on):
-    """Test hook: tap-fused 3x3 implicit-GEMM variant on / off (process-wide)."""
-    _lib.load().yolo2_debug_set_igemm_tap(int(bool(on)))
+def set_igemm_tap(mode):
+    """Test hook: tap-fused 3x3 implicit-GEMM variant (process-wide): 0 none, 1 round-2 tap-fused kernel, 2 ping-pong kernel (default)."""
+    _lib.load().yolo2_debug_set_igemm_tap(int(mode))
+
+
+def set_pp(grid=-1, dmapos=-1, min_steps=-1, min_share=-1):
+    """Test / A-B hook for the ping-pong kernel (include/yolo2_hip.h yolo2_debug_set_pp); negative = keep."""
+    _lib.load().yolo2_debug_set_pp(int(grid), int(dmapos), int(min_steps), int(min_share))
 
 
 def last_wgrad_plan():
