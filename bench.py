@@ -156,16 +156,21 @@ def cpu_baseline(names, size, budget_s=30.0):
         R.train_step(spec, params, {}, x, labels, names, anchors, hp, 1e-6, 0)
         t_total += time.time() - t0
         n += 1
-    out = {'value': n / t_total, 'unit': 'img/s', 'cores': int(threads), 'kind': 'port',
-           'sample': '%d single-image 416x416 Darknet-19 training steps (fwd+loss+bwd+Adam) of oracle/yolo2_ref.py, NumPy/BLAS f32, %.1f s; '
-                     'CPU restatement of reference semantics (TensorFlow 1.0 unavailable)' % (n, t_total),
-           'host_cores': os.cpu_count()}
-    # conv stack on torch-CPU (oneDNN, NHWC f32) at the reference's default batch 8 (train.py:156)
+    port = {'value': n / t_total, 'unit': 'img/s', 'cores': int(threads),
+            'sample': '%d single-image 416x416 Darknet-19 training steps (fwd+loss+bwd+Adam) of oracle/yolo2_ref.py, NumPy/BLAS f32, %.1f s; '
+                      'CPU restatement of reference semantics (TensorFlow 1.0 unavailable)' % (n, t_total)}
+    out = dict(port, kind='port', host_cores=os.cpu_count())
+    # conv stack on torch-CPU (oneDNN, NHWC f32) at the reference's default batch 8 (train.py:156) -- the closest stand-in for
+    # TF-1.0's CPU kernels this image can run, and the faster of the two CPU legs: it is the headline `value`; the NumPy port stays beside it
     try:
         from oracle import torch_cpu_ref as T
         r = T.time_conv_stack(classes=names, size=size, batch=8, budget_s=12.0)
         out['torch_cpu_conv_stack'] = {'fwd_img_s': r['fwd_img_s'], 'train_img_s': r['train_img_s'], 'batch': 8, 'threads': r['threads'],
                                        'sample': '%d forward / %d forward+backward passes, Darknet-19 %dx%d f32 channels_last' % (r['fwd_iters'], r['train_iters'], size, size)}
+        out.update({'value': r['train_img_s'], 'cores': int(r['threads']), 'numpy_port': port,
+                    'sample': '%d forward+backward passes of the Darknet-19 conv stack at batch 8, %dx%d f32 channels_last, torch-CPU / oneDNN '
+                              '(oracle/torch_cpu_ref.py: a CPU port of the same layer stack; no loss / optimizer, which are < 1 %% of the step)'
+                              % (r['train_iters'], size, size)})
     except Exception as exc:       # a baseline leg must never take the GPU numbers down with it
         out['torch_cpu_conv_stack'] = {'error': repr(exc)}
     # the reference's NMS algorithm (utils/postprocess.py:39-51), single thread like the reference, C restatement
@@ -353,19 +358,20 @@ def main():
         ks = timer.summary(('fwd', 'dgrad')) if timer else None       # the 3x3 launches of the implicit-GEMM kernel
         if ks:
             kf, kd, k1 = timer.summary('fwd'), timer.summary('dgrad'), timer.summary('1x1')
-            out['roofline'] = {'bound': 'mfma', 'achieved': ks['tflops'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': ks['tflops'] / peak,
+            raw_tflops = ks['tflops'] * ks['total_ms'] / (ks['raw_bracket_avg_ms'] * ks['launches'])      # from the uncorrected brackets (= the rocprofv3 average to 0.5 %)
+            out['roofline'] = {'bound': 'mfma', 'achieved': raw_tflops, 'peak': peak, 'unit': 'TFLOP/s', 'frac': raw_tflops / peak,
                                'traffic': IGEMM_HBM_BYTES_PER_LAUNCH if (args.dtype == 'bf16' and args.batch == 16 and args.size == 416) else None,
-                               'kernel': 'conv_igemm_kernel<%s, BN=128, KS=3, ...> + conv3x3_tap_kernel<...> (the 3x3 implicit-GEMM forward + data-gradient '
-                                         'convolutions with > 64 filters: the "3x3 convs" of the north-star target; the tap-fused kernel takes the '
-                                         '>= 1024-channel 13x13 layers)' % args.dtype,
+                               'kernel': 'conv3x3_pp_kernel<...> + conv_igemm_kernel<%s, BN=128, KS=3, ...> (the 3x3 implicit-GEMM forward + data-gradient '
+                                         'convolutions with > 64 filters: the "3x3 convs" of the north-star target; the ping-pong tap-fused kernel takes the '
+                                         'layers on images up to 55 wide, the per-tap kernel the 104x104 stage)' % args.dtype,
                                'sustained_mfma_peak_note': 'a pure v_mfma_f32_32x32x16_bf16 loop sustains 1.9-2.1 PFLOP/s on these boxes (power-limited clock, '
                                                            'profiles/r02_igemm_tap.md); peak above is the 2.4 GHz datasheet figure',
-                               'launches': ks['launches'], 'avg_launch_ms': ks['avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
+                               'launches': ks['launches'], 'avg_launch_ms': ks['raw_bracket_avg_ms'], 'algorithmic_flop_per_launch': ks['flop_per_launch'],
                                'event_bracket': {'raw_avg_ms': ks['raw_bracket_avg_ms'], 'overhead_ms': timer.bracket_overhead_ms,
-                                                 'around_empty_kernel_ms': timer.bracket_noop_ms,
-                                                 'note': 'avg_launch_ms = HIP-event bracket minus the dispatch latency a bracket adds, calibrated on '
-                                                         'brackets around an empty kernel (its own 3.4 us excluded); frac from the raw brackets: %.4f'
-                                                         % (ks['tflops'] * ks['total_ms'] / (ks['raw_bracket_avg_ms'] * ks['launches']) / peak)},
+                                                 'around_empty_kernel_ms': timer.bracket_noop_ms, 'calibrated_avg_ms': ks['avg_ms'],
+                                                 'calibrated_tflops': ks['tflops'], 'calibrated_frac': ks['tflops'] / peak,
+                                                 'note': 'achieved / frac / avg_launch_ms come from the RAW HIP-event brackets; the calibrated figures subtract '
+                                                         'the dispatch latency a bracket adds (measured on brackets around an empty kernel, its own 3.4 us excluded)'},
                                'algorithmic_bytes_per_launch': IGEMM_ALGORITHMIC_BYTES_PER_LAUNCH, 'traffic_unit': 'bytes per launch (PMC, separate passes)',
                                'traffic_source': {'file': 'profiles/dominant_kernel_pmc.json', 'measured_at_commit': PMC['measured_at_commit']},
                                'measured_over': '%d instrumented single-stream training steps run right after the timed region '
@@ -428,8 +434,7 @@ def multiscale(args, rank, world, basedir, dist):
         # per-bucket collective and EXPOSED time (how long the optimizer's stream waited for each bucket), from a few instrumented steps
         # after the timed region: makes the first multi-GPU run diagnosable (which bucket is not hidden behind backward / the update)
         sess.reducer.timing = True
-        for _ in range(3):
-            sess.step(images)
+        run(3)
         torch.cuda.synchronize()
         comm_report = sess.reducer.exposed_times()
         sess.reducer.timing = False
@@ -444,13 +449,14 @@ def multiscale(args, rank, world, basedir, dist):
             'config': {'workload': 'Darknet-19 YOLOv2 multi-scale training, input size cycled over %s, batch %d per GPU (BASELINE configs[3])' % (sizes, batch),
                        'global_batch': world * batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)'},
             'whole_step_tflops': gflop / elapsed / 1e3, 'whole_step_frac_of_mfma_peak': gflop / elapsed / 1e3 / peak / world,
+            'comm': None if comm_report is None else {'buckets': comm_report, 'exposed_ms_per_step': sum(b['exposed_ms'] or 0.0 for b in comm_report)},
             'total_loss': loss['total_loss']}), flush=True)
     barrier()
     if world > 1:
         dist.destroy_process_group()
 
 
-def detect_latency(args, basedir, batch=256, iters=30):
+def detect_latency(args, basedir, batch=256, iters=200):
     """BASELINE configs[4]: batch-256 416x416 detect (standardise + forward + decode + on-GPU NMS), p50/p99 latency.
     Random-init weights give conf ~ 0.5/C << 0.3, so the network's own scores leave the NMS nothing to suppress; the figure
     that includes real NMS work overwrites the decoded boxes with the stress inputs of BASELINE.md section 2 (sparse

@@ -178,7 +178,10 @@ int yolo2_bn_finalize(float *bn_part, const float *shift, long M, int C, float *
  * prologue beats a separate finalisation launch); otherwise use yolo2_bn_finalize / yolo2_bn_part_to_grads / the plain pairs.
  * The rows are only READ here.  zero / zero_floats (multiple of 4, 16-byte aligned; may be NULL / 0): a float range this launch
  * clears on the side -- the engine keeps two partial buffers and has each consumer clear the one its predecessor finished with, so
- * every producer finds zero rows without a memset launch.  Results equal the two-launch forms up to f64 summation order. */
+ * every producer finds zero rows without a memset launch.  Results equal the two-launch forms up to f64 summation order.
+ * `shift` (the per-channel values the producer subtracted) is read by EVERY workgroup of the launch while the first workgroup of each
+ * channel slice stores mean / var and updates moving_mean / moving_var in place: it must not alias any of them (YOLO2_E_ARG if it
+ * does).  A caller that shifts by the moving mean hands in a copy taken before the step (engine.Engine.state_snap). */
 /* yolo2_bn_leaky_pool_fin: ymax (optional, [B*(H/2)*(W/2)][C], dense) receives the raw convolution output AT the arg-max of each
  * window.  Only arg-max positions carry gradient, so the layer's backward reduction is then yolo2_bn_leaky_bwd_reduce_part over
  * (dP, ymax) at the POOLED resolution: a quarter of the rows, and neither Y nor idx are read.  A_full (optional, dense [B*H*W][C])

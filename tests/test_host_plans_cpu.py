@@ -99,3 +99,49 @@ def test_arena_layout_alignment_and_bucket_bounds():
     assert buckets[0][0] == 0 and buckets[-1][1] == off
     assert all(s in starts and e in starts and e > s for s, e in buckets)
     assert all(b[1] == n[0] for b, n in zip(buckets, buckets[1:]))
+
+
+def test_checkpoint_restore_remaps_optimizer_slots_when_only_the_arena_offsets_moved(tmp_path):
+    """A checkpoint written with another arena alignment (same variables, other offsets) keeps its Adam moments: they are moved
+    variable by variable.  A different variable set still starts fresh."""
+    import numpy as np
+    import torch
+    from yolo_tf_amd import checkpoint
+
+    class Eng(object):
+        def __init__(self, offsets):
+            self.param_offsets = offsets
+            self.vals = {}
+
+        def get_variables(self):
+            return self.vals
+
+        def set_variables(self, values, strict=True):
+            self.vals = dict(values)
+
+    class Opt(object):
+        name = 'adam'
+
+        def __init__(self, n):
+            self.slots = [torch.zeros(n), torch.zeros(n)]
+
+    class Sess(object):
+        def __init__(self, offsets, n):
+            self.engine, self.optimizer, self.global_step = Eng(offsets), Opt(n), 0
+
+    old = Sess({'a/w': (0, 5), 'b/w': (8, 3)}, 12)          # 4-element alignment
+    old.engine.vals = {'a/w': np.arange(5, dtype=np.float32), 'b/w': np.ones(3, np.float32)}
+    old.optimizer.slots[0][:] = torch.arange(12.0)
+    old.optimizer.slots[1][:] = torch.arange(12.0) * 10
+    old.global_step = 7
+    path = checkpoint.save(str(tmp_path), old)
+    new = Sess({'a/w': (0, 5), 'b/w': (64, 3)}, 80)         # 64-element alignment
+    assert checkpoint.restore(path, new) == 7 and new.global_step == 7
+    for k, slot in enumerate(new.optimizer.slots):
+        scale = 10 ** k
+        assert slot[0:5].tolist() == [float(i * scale) for i in range(5)] and slot[64:67].tolist() == [float(i * scale) for i in (8, 9, 10)]
+        assert float(slot[5:64].abs().sum()) == 0.0
+    other = Sess({'a/w': (0, 5), 'c/w': (64, 3)}, 80)
+    other.optimizer.slots[0][:] = 1.0
+    checkpoint.restore(path, other)
+    assert float(other.optimizer.slots[0].sum()) == 80.0   # untouched: layouts name different variables

@@ -710,6 +710,53 @@ def _host_partials(vals0, vals1, rows, C, plane_rows, rng, poison):
     return part
 
 
+def test_bn_leaky_fin_shift_is_read_only_across_thousands_of_workgroups(ops):
+    """Round-3 advisor finding: the engine handed the LIVE moving mean to yolo2_bn_leaky_fin both as `shift` (read by every workgroup
+    after its prologue) and as `moving_mean` (updated in place by the first workgroup of each channel slice) -- late workgroups
+    normalised with a mean off by (1 - decay) * (batch mean - moving mean).  The ABI now rejects the aliased call; with the snapshot
+    the engine passes (engine.Engine.state_snap) a launch of ~2700 workgroups per slice equals yolo2_bn_finalize + yolo2_bn_leaky
+    (to an f32 ulp of the moments) and is deterministic, with a decay small enough that a stale read would move the mean by 30 % of the offset."""
+    B, H, W, C, rows = 16, 104, 104, 128, 16
+    M = B * H * W
+    T = torch.bfloat16
+    rng = np.random.RandomState(11)
+    y = bf16_round((rng.randn(M, C) * 1.5 + rng.randn(C) * 2.0).astype(np.float32))
+    mm0 = (y.mean(0) + 3.0 + rng.randn(C)).astype(np.float32)       # a moving mean far from the batch mean: a stale read is visible
+    d = y - mm0
+    part = _host_partials(d, d * d, rows, C, 256, rng, poison=True)
+    yd, g, b_ = dev(y, T), dev((rng.rand(C) + 0.5).astype(np.float32)), dev((rng.randn(C) * 0.2).astype(np.float32))
+    decay = 0.7
+    # two-launch reference: finalize (zeroes its partial rows) + apply
+    mean_r, var_r = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    mm_r, mv_r = dev(mm0), torch.ones(C, device='cuda')
+    A_r = torch.zeros(M * C, dtype=T, device='cuda')
+    ops.bn_finalize(dev(part), dev(mm0), M, C, mean_r, var_r, mm_r, mv_r, decay)
+    ops.bn_leaky(yd, mean_r, var_r, g, b_, A_r, M, C, C, 1e-5, 0.1)
+    for rep in range(3):
+        mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+        mm, mv = dev(mm0), torch.ones(C, device='cuda')
+        A = torch.zeros(M * C, dtype=T, device='cuda')
+        ops.bn_leaky_fin(yd, dev(part), rows, dev(mm0), mean, var, mm, mv, decay, g, b_, A, M, C, C, 1e-5, 0.1)
+        torch.cuda.synchronize()
+        # (the two forms add the same f64 partial sums in different orders: equal to an f32 ulp, in practice identical)
+        np.testing.assert_allclose(host(mean), host(mean_r), rtol=3e-7, atol=0)
+        np.testing.assert_allclose(host(var), host(var_r), rtol=3e-7, atol=0)
+        np.testing.assert_allclose(host(mm), host(mm_r), rtol=3e-7, atol=0)
+        np.testing.assert_allclose(host(mv), host(mv_r), rtol=3e-7, atol=0)
+        nbad = int((A != A_r).sum())
+        assert nbad <= (0 if torch.equal(mean, mean_r) and torch.equal(var, var_r) else M * C // 1000), \
+            'repeat %d: %d elements differ from the two-launch form' % (rep, nbad)
+        if rep == 0:
+            A0 = A
+        assert torch.equal(A, A0), 'repeat %d differs from repeat 0: the launch is not deterministic' % rep
+    mm = dev(mm0)
+    with pytest.raises(RuntimeError):
+        ops.bn_leaky_fin(yd, dev(part), rows, mm, mean, var, mm, mv, decay, g, b_, A, M, C, C, 1e-5, 0.1)
+    P = torch.zeros(B * (H // 2) * (W // 2) * C, dtype=T, device='cuda')
+    with pytest.raises(RuntimeError):
+        ops.bn_leaky_pool_fin(yd, dev(part), rows, mm, mean, var, mm, mv, decay, g, b_, P, None, B, H, W, C, C, 1e-5, 0.1)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape,rows', [((2, 26, 26, 32), 256), ((4, 13, 13, 1024), 44), ((1, 52, 52, 64), 128), ((2, 26, 26, 512), 16), ((3, 8, 6, 8), 5),
                                         ((2, 14, 14, 256), 64)])
@@ -1061,7 +1108,8 @@ def _c_nms(conf, mn, mx, thr, thr_iou):
     return conf, order
 
 
-@pytest.mark.parametrize('B,N,C,dense', [(8, 845, 20, False), (4, 845, 80, False), (2, 845, 20, True), (2, 1805, 20, False), (3, 100, 3, True)])
+@pytest.mark.parametrize('B,N,C,dense', [(8, 845, 20, False), (4, 845, 80, False), (2, 845, 20, True), (2, 1805, 20, False), (3, 100, 3, True),
+                                         (1, 4096, 4, False), (1, 4001, 2, True)])      # the documented N limit (129 KB of LDS)
 def test_nms_batched_vs_c_oracle(ops, B, N, C, dense):
     rng = np.random.RandomState(N + C)
     if dense:

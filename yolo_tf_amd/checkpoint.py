@@ -75,7 +75,20 @@ def restore(path, session=None, engine=None, exclude=None, variables_only=False)
         if str(z['optimizer']) != session.optimizer.name:
             logging.warning('%s was written by optimizer %s: %s slots start fresh', path, z['optimizer'], session.optimizer.name)
         elif not same_layout:
-            logging.warning('%s has a different parameter layout: optimizer slots start fresh', path)
+            # Same variables at other offsets (the arena's alignment changed between builds): move the moments variable by variable.
+            # Anything else (another model, class count, variable set) would misalign them: start fresh.
+            saved = {str(k): (int(o), int(n)) for o, n, k in z['param_layout']} if 'param_layout' in z.files else {}
+            cur = engine.param_offsets
+            if saved and set(saved) == set(cur) and all(saved[k][1] == cur[k][1] for k in cur):
+                for i, s in enumerate(session.optimizer.slots):
+                    old = z['slot/%d' % i]
+                    new = np.zeros(s.numel(), old.dtype)
+                    for k, (o, n) in cur.items():
+                        new[o:o + n] = old[saved[k][0]:saved[k][0] + n]
+                    s.copy_(torch.from_numpy(new))
+                logging.info('%s: optimizer slots remapped to the current arena offsets', path)
+            else:
+                logging.warning('%s has a different parameter layout: optimizer slots start fresh', path)
         else:
             for i, s in enumerate(session.optimizer.slots):
                 s.copy_(torch.from_numpy(z['slot/%d' % i]))

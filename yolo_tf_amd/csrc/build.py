@@ -33,7 +33,7 @@ def _stale(out, deps):
 
 
 def build(force=False, verbose=True):
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc = os.environ.get('HIPCC', os.path.join(ROCM, 'bin', 'hipcc'))
     headers = [os.path.join(HERE, 'common.h'), os.path.join(HERE, 'conv_shared.h'), os.path.join(HERE, '..', '..', 'include', 'yolo2_hip.h'), os.path.abspath(__file__)]
     objs = []
     for src, extra in SOURCES.items():
@@ -53,14 +53,22 @@ def build(force=False, verbose=True):
         # fails here (not on the GPU box) if any symbol is unresolved.  In a child process: dlopen()ing the library in THIS
         # process before torch is imported would map a second HIP runtime next to torch's bundled one (see _lib.load)
         subprocess.check_call([sys.executable, '-c', 'import ctypes, sys; ctypes.CDLL(sys.argv[1])', LIB])
-    build_comm(force=force, verbose=verbose)
+    # the communicator library is optional: a ROCm install without RCCL development files still gets the single-GPU library (the Python
+    # host uses torch's own RCCL; only C / C++ hosts that want data parallelism need libyolo2comm.so)
+    if os.path.exists(os.path.join(ROCM, 'include', 'rccl', 'rccl.h')) or os.path.exists(os.path.join(ROCM, 'include', 'rccl.h')):
+        try:
+            build_comm(force=force, verbose=verbose)
+        except subprocess.CalledProcessError as exc:
+            print('warning: libyolo2comm.so not built (%s); include/yolo2_comm.h hosts are unavailable' % exc, file=sys.stderr)
+    elif verbose:
+        print('note: no rccl.h under %s: libyolo2comm.so skipped' % ROCM, file=sys.stderr)
     return LIB
 
 
 def build_comm(force=False, verbose=True):
     """libyolo2comm.so: host code only (RCCL launches its own kernels).  A separate shared object on purpose: it links /opt/rocm's
     librccl, and the Python host (torch.distributed, torch's own RCCL) must not map it -- see include/yolo2_comm.h."""
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    hipcc = os.environ.get('HIPCC', os.path.join(ROCM, 'bin', 'hipcc'))
     src = os.path.join(HERE, 'comm.cpp')
     hdr = os.path.join(HERE, '..', '..', 'include', 'yolo2_comm.h')
     if force or _stale(COMM_LIB, [src, hdr, os.path.abspath(__file__)]):

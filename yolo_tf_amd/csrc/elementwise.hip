@@ -1899,6 +1899,7 @@ extern "C" int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows,
                                   float alpha, float *zero, long zero_floats, int dtype, void *stream) {
     Y2_CHECK_ARG(Y && bn_part && shift && mean && var && gamma && beta && A && M > 0 && C > 0 && lda >= C && M < (1L << 31));
     Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr) && rows <= Y2_BN_PART_ROWS && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ARG(shift != moving_mean && shift != mean);      // every workgroup reads the shift; one per channel slice writes these (see the header)
     Y2_CHECK_ZERO(zero, zero_floats);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(lda % vec == 0);
@@ -1916,6 +1917,7 @@ extern "C" int yolo2_bn_leaky_pool_fin(const void *Y, const float *bn_part, int 
     Y2_CHECK_ARG(Y && bn_part && shift && mean && var && gamma && beta && P && ldp >= C);
     Y2_CHECK_ARG(pool_args_ok(B, H, W, C, dtype) && ldp % (dtype == YOLO2_BF16 ? 8 : 4) == 0);
     Y2_CHECK_ARG((moving_mean == nullptr) == (moving_var == nullptr) && rows <= Y2_BN_PART_ROWS && fin_shape_ok(rows, C, dtype));
+    Y2_CHECK_ARG(shift != moving_mean && shift != mean);
     Y2_CHECK_ZERO(zero, zero_floats);
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     const dim3 grid = slice_grid((long)B * (H / 2) * (W / 2), C, vec, 2, rows);

@@ -35,13 +35,15 @@ __global__ __launch_bounds__(256) void nms_kernel(float *__restrict__ conf, cons
                                                   const float *__restrict__ xy_max, int *__restrict__ order_out, int N, int C,
                                                   float thr, float thr_iou, int NP) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float *key = reinterpret_cast<float *>(smem_raw);      // [N] original scores of this class (box order)
-    float *skey = key + N;                                  // [N] scores in sorted order
+    float *skey = reinterpret_cast<float *>(smem_raw);     // [N] scores in sorted order
     int *sidx = reinterpret_cast<int *>(skey + N);          // [N] sorted position -> box index
-    f32x4 *sbox = reinterpret_cast<f32x4 *>(sidx + N + ((4 - (3 * N) % 4) % 4));  // [N] (minx,miny,maxx,maxy), 16-B aligned
-    int *perm = reinterpret_cast<int *>(sbox + N);          // [NP] box indices being sorted (-1 = padding, sorts last); NP = pow2 >= N
-    int *cnt = perm + NP;                                   // [256] candidates per thread range
-    unsigned long long *rows = reinterpret_cast<unsigned long long *>(cnt + 256);      // [Y2_NMS_GROUP][nchunks] overlap words of one candidate group
+    f32x4 *sbox = reinterpret_cast<f32x4 *>(sidx + N + ((4 - (2 * N) % 4) % 4));  // [N] (minx,miny,maxx,maxy), 16-B aligned
+    float *key = reinterpret_cast<float *>(sbox + N);       // [N] original scores of this class (box order): sort phase only
+    int *perm = reinterpret_cast<int *>(key + N);           // [NP] box indices being sorted (-1 = padding, sorts last); NP = pow2 >= N: sort phase only
+    int *cnt = perm + NP;                                   // [256] candidates per thread range: sort phase only
+    // [Y2_NMS_GROUP][nchunks] overlap words of one candidate group: the scan's only scratch, laid over the sort phase's (key, perm, cnt),
+    // which are dead by then (4 N + 4 NP + 1024 >= 8 (64 nchunks + 1) bytes; with its own storage N = 4096 asked for 166 KB of the 160 KB LDS)
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(key);
 
     const int b = blockIdx.x / C, c = blockIdx.x % C;
     const long base = (long)b * N;
@@ -172,14 +174,20 @@ extern "C" int yolo2_nms(float *conf, const float *xy_min, const float *xy_max, 
     int NP = 2;                       // (even: keeps the 8-byte words behind perm[] aligned)
     while (NP < N) NP <<= 1;
     const size_t nchunks = ((size_t)N + 63) / 64;
-    const size_t lds = sizeof(float) * 3 * (size_t)N + 16 + sizeof(float) * 4 * (size_t)N + sizeof(int) * ((size_t)NP + 256) + 8 * (64 * nchunks + 1);
-    static size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            yolo2_set_error("nms: cannot reserve %zu bytes of LDS", lds);
-            return YOLO2_E_LAUNCH;
+    (void)nchunks;
+    const size_t lds = sizeof(float) * 3 * (size_t)N + 16 + sizeof(float) * 4 * (size_t)N + sizeof(int) * ((size_t)NP + 256);      // <= 129 KB at N = 4096
+    if (lds > 64 * 1024) {
+        // the attribute is per device: remember what each device of this process has been raised to (a second GPU never inherited the first one's limit)
+        static size_t lds_set[64] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
+        if (dev < 0 || lds > lds_set[dev]) {
+            if (hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                yolo2_set_error("nms: cannot reserve %zu bytes of LDS", lds);
+                return YOLO2_E_LAUNCH;
+            }
+            if (dev >= 0) lds_set[dev] = lds;
         }
-        lds_set = lds;
     }
     nms_kernel<<<B * C, 256, lds, st>>>(conf, (const float *)ws, xy_min, xy_max, order_out, N, C, threshold, threshold_iou, NP);
     Y2_CHECK_LAUNCH();

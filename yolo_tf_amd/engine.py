@@ -155,6 +155,12 @@ class Engine(object):
             self.state_offsets[v.name] = (off, v.size)
             off += (v.size + 3) // 4 * 4
         self.state = torch.zeros(max(off, 4), dtype=torch.float32, device=self.device)
+        # Snapshot of the non-trainable state taken at the start of every training forward.  The convolution epilogues and the
+        # consumers that finish the batch statistics (yolo2_bn_leaky_fin & co.) shift their sums by svar[moving_mean]: reading the live
+        # moving mean would race with the workgroup that updates it in place (thousands of workgroups read the shift after their
+        # prologue; the first one of each channel slice writes the moving average).
+        self.state_snap = torch.zeros_like(self.state)
+        self.svar = {}
         self.var = {}
         self.gvar = {}
         for name, (o, n) in self.param_offsets.items():
@@ -163,6 +169,7 @@ class Engine(object):
                 self.gvar[name] = self.grads[o:o + n]
         for name, (o, n) in self.state_offsets.items():
             self.var[name] = self.state[o:o + n]
+            self.svar[name] = self.state_snap[o:o + n]
         # per-tensor segments (for clip_by_norm) in buffer order
         segs = sorted(self.param_offsets.values())
         self.seg_off = torch.tensor([s[0] for s in segs] + [self.n_params], dtype=torch.int64, device=self.device)
@@ -491,6 +498,8 @@ class Engine(object):
     def forward(self):
         self._prepare_filters()
         B = self.B
+        if self.training:
+            self.state_snap.copy_(self.state)        # this step's shifts (see _alloc_variables)
         pooled = set()               # pool ops already produced by their producer's BN pass in this sweep
         for op in self.graph.ops:
             kind = op['kind']
@@ -524,8 +533,9 @@ class Engine(object):
                     gamma, beta = self.var[op['gamma'].name], self.var[op['beta'].name]
                     mmean, mvar = self.var[op['moving_mean'].name], self.var[op['moving_variance'].name]
                     fused = self.training and self.fuse_bn_stats and ldy == op['cout']
+                    shift = self.svar[op['moving_mean'].name]       # the moving mean as of the start of this step (read-only during the step)
                     produced = self._conv(xb, st['Ffwd'], None, yb, x.h, x.w, pad8(x.c), ldx, op['cout'], ldy, op['ksize'], op['ksize'] ** 2 * op['cin'],
-                                          bn_shift=mmean if fused else None)
+                                          bn_shift=shift if fused else None)
                     fin = None
                     if fused:
                         # batch moments from the partial sums the convolution left behind (shift = the moving mean)
@@ -535,7 +545,7 @@ class Engine(object):
                         else:
                             if self.sync_bn and self.bn_world > 1:
                                 self._sync_bn_sums(self.parts.bufs[part], op['cout'])
-                            ops.bn_finalize(self.parts.bufs[part], mmean, M * (self.bn_world if self.sync_bn else 1), op['cout'], st['mean'], st['var'],
+                            ops.bn_finalize(self.parts.bufs[part], shift, M * (self.bn_world if self.sync_bn else 1), op['cout'], st['mean'], st['var'],
                                             mmean, mvar, BN_DECAY)
                             self.parts.consumed(part, cleared=True)
                         mean, var = st['mean'], st['var']
@@ -551,17 +561,17 @@ class Engine(object):
                         zbuf, zn = self.parts.take_to_zero(part)
                         if pool is not None:
                             pb, ldp = self.act[pool['out']]
-                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, st.get('pool_idx'),
+                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, shift, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, st.get('pool_idx'),
                                                   B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn, ymax=st.get('pool_ymax'))
                             st['ymax_valid'] = 'pool_ymax' in st
                         elif out in self.fwd_pool:        # both resolutions from one pass (the activation has a second reader)
                             pb, ldp = self.act[self.fwd_pool[out]['out']]
-                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, None,
+                            ops.bn_leaky_pool_fin(yb, self.parts.bufs[part], rows, shift, mean, var, mmean, mvar, BN_DECAY, gamma, beta, pb, None,
                                                   B, out.h, out.w, op['cout'], ldp, BN_EPS, LEAKY_ALPHA, zbuf, zn, a_full=self.act[out][0])
                             pooled.add(self.fwd_pool[out]['name'])
                         else:
                             ob, ldo = self.act[out]
-                            ops.bn_leaky_fin(yb, self.parts.bufs[part], rows, mmean, mean, var, mmean, mvar, BN_DECAY, gamma, beta, ob, M, op['cout'], ldo,
+                            ops.bn_leaky_fin(yb, self.parts.bufs[part], rows, shift, mean, var, mmean, mvar, BN_DECAY, gamma, beta, ob, M, op['cout'], ldo,
                                              BN_EPS, LEAKY_ALPHA, zbuf, zn)
                         self.parts.consumed(part)
                     elif pool is not None:

@@ -44,7 +44,9 @@ class TrainSession(object):
         e = self.engine
         if e.sync_bn:                # batch moments and BN-backward sums over all replicas ([mi355x] sync_bn; default: replica-local like N reference processes)
             import torch.distributed as dist
-            e.bn_group, e.bn_world = dist.group.WORLD, int(world_size)
+            # a group of its own: a process group's collectives run in order on one internal stream, so the small per-layer BN exchanges
+            # would otherwise queue behind whatever 64 MB gradient bucket is on the wire (every rank builds its session: new_group is collective)
+            e.bn_group, e.bn_world = (dist.new_group() if dist.is_initialized() else dist.group.WORLD), int(world_size)
         self.models = {wh: gm[1] for wh, gm in traced.items()}
         m0 = traced[largest][1]
         self.A, self.C = (m0.boxes_per_cell if self.v1 else len(m0.anchors)), m0.classes
