@@ -1,6 +1,7 @@
 """Per-layer A/B of the 3x3 implicit-GEMM variants on the Darknet-19 shapes (bf16): per-tap kernels (mode 0), the round-2 tap-fused kernel
-where its gates admit it (mode 1) and the ping-pong kernel (mode 2) as stream-K / one workgroup per tile, DMA at the head of the LOAD
-phase / inside the MFMA phase.  usage: B=16 python scripts/pp_sweep.py   -> us | TFLOP/s per launch, one box, hipGraph-replayed."""
+where its gates admit it (mode 1) and the ping-pong kernel (mode 2) as stream-K / one workgroup per tile with its SCHED variants
+(conv_pp.hip).  Every configuration's outputs are also compared with the per-tap kernels' on the same operands (max |diff| / max |ref|).
+usage: B=16 [LAYERS=conv8,conv20] [CONFIGS=name:mode:grid:sched,...] python scripts/pp_sweep.py   -> us | TFLOP/s per launch, one box, hipGraph-replayed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +12,10 @@ if os.environ.get('LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['LAYERS'].split(',')]
 B = int(os.environ.get('B', 16))
 T = torch.bfloat16
-CONFIGS = [('per-tap', 0, 0, 0), ('tap-r2', 1, 0, 0), ('pp-sk-d0', 2, 1, 0), ('pp-sk-d1', 2, 1, 1), ('pp-tile-d0', 2, 2, 0), ('pp-tile-d1', 2, 2, 1)]
+CONFIGS = [('per-tap', 0, 0, 0), ('tap-r2', 1, 0, 0), ('pp-sk', 2, 1, -1), ('pp-tile', 2, 2, -1)]      # sched -1 = the library default
+if os.environ.get('CONFIGS'):
+    CONFIGS = [(c.split(':')[0],) + tuple(int(v) for v in c.split(':')[1:]) for c in os.environ['CONFIGS'].split(',')]
+WHAT = os.environ.get('WHAT', 'fwd+stats,dgrad,dgrad+bn').split(',')
 
 
 def timeit(fn):
@@ -40,7 +44,7 @@ def timeit(fn):
 
 
 ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
-print('batch %d; columns: %s   (us|TFLOP/s, plan BM/stages/grid)' % (B, ', '.join(c[0] for c in CONFIGS)))
+print('batch %d; columns: %s   (us|TFLOP/s plan BM/stages/grid, rel. difference to the first column)' % (B, ', '.join('%s[%d/%d/%d]' % c for c in CONFIGS)))
 for name, H, cin, cout in LAYERS:
     M = B * H * H
     x = torch.randn(M * cin, device='cuda').to(T)
@@ -59,20 +63,33 @@ for name, H, cin, cout in LAYERS:
     red = torch.zeros(ops.workspace_bytes('bn', cin) // 8, dtype=torch.float64, device='cuda')
     ops.filter_prep(w, Ff, Fd, 3, cin, cin, cout, cout, T)
     fl = 2.0 * M * 9 * cin * cout
-    rows = {'fwd+stats': [], 'dgrad': [], 'dgrad+bn': []}
-    for cname, mode, grid, dmapos in CONFIGS:
+    calls = {'fwd+stats': (lambda: ops.conv2d_bn(x, Ff, y, ws, B, H, H, cin, cin, cout, cout, 3, shift, part), y),
+             'dgrad': (lambda: ops.conv2d_ws(dy, Fd, None, dx, ws, B, H, H, cout, cout, cin, cin, 3), dx),
+             'dgrad+bn': (lambda: ops.conv2d_dgrad_bn(dy, Fd, dx, ws, B, H, H, cout, cout, cin, cin, 3, yprev, pm, pv, pg, pb, dg, db, part, red, 1e-3, 0.1), dx)}
+    rows = {k: [] for k in WHAT}
+    ref = {}
+    for cname, mode, grid, sched in CONFIGS:
         ops.set_igemm_tap(mode)
-        ops.set_pp(grid=grid, dmapos=dmapos, min_steps=0, min_share=0)
-        for what, fn in (('fwd+stats', lambda: ops.conv2d_bn(x, Ff, y, ws, B, H, H, cin, cin, cout, cout, 3, shift, part)),
-                         ('dgrad', lambda: ops.conv2d_ws(dy, Fd, None, dx, ws, B, H, H, cout, cout, cin, cin, 3)),
-                         ('dgrad+bn', lambda: ops.conv2d_dgrad_bn(dy, Fd, dx, ws, B, H, H, cout, cout, cin, cin, 3, yprev, pm, pv, pg, pb, dg, db, part, red, 1e-3, 0.1))):
+        ops.set_pp(grid=grid, dmapos=sched, min_steps=0, min_share=0)
+        for what in WHAT:
+            fn, out = calls[what]
             try:
+                if (sched & 32) and sched >= 0 and what != 'dgrad':
+                    rows[what].append('-')
+                    continue
+                out.zero_()
                 t = timeit(fn)
                 p = ops.last_conv_plan()
-                rows[what].append('%6.1f|%4.0f %d/%d/%d' % (t, fl / t / 1e6, p['BM'], p['stages'], p['grid_x']))
+                o = out.float()
+                if what not in ref:
+                    ref[what] = o
+                    diff = 0.0
+                else:
+                    diff = float((o - ref[what]).abs().max() / ref[what].abs().max())
+                rows[what].append('%6.1f|%4.0f %d/%d/%d %.0e' % (t, fl / t / 1e6, p['BM'], p['stages'], p['grid_x'], diff))
             except Exception as e:      # noqa
                 rows[what].append('ERR %s' % str(e)[:40])
     for what in rows:
         print('%-7s %-9s %s' % (name, what, '   '.join(rows[what])), flush=True)
 ops.set_igemm_tap(2)
-ops.set_pp(grid=0, dmapos=0, min_steps=18, min_share=12)
+ops.set_pp(grid=0, dmapos=-1, min_steps=18, min_share=12)

@@ -203,8 +203,9 @@ def _bn_bwd_sums_oracle(dA, yprev, mean, var, gamma, beta, eps, alpha=0.1):
 TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 256), (8, 13, 13, 1024, 504), (16, 26, 26, 256, 136),
               (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256),
               (3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
-# variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong DMA position)
-TAP_VARIANTS = {'tap': (1, 0, 0), 'pp': (2, 1, 0), 'pp_tiles': (2, 2, 0), 'pp_dma1': (2, 1, 1)}
+# variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong SCHED (-1 = the default))
+TAP_VARIANTS = {'tap': (1, 0, -1), 'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1)}
+_TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant and epilogue: minutes of CPU time when recomputed 12 times)
 
 
 @pytest.mark.parametrize('epilogue', ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn'])
@@ -230,7 +231,7 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
     out = {}
     for tap in (0, 1):
         ops.set_igemm_tap(mode if tap else 0)     # (the round-2 kernel: run with YOLO2_IGEMM_TAP_MIN_STEPS=0 YOLO2_IGEMM_TAP_MIN_SHARE=12 to force the short reductions through it too)
-        ops.set_pp(grid=pp_grid, dmapos=pp_dma, min_steps=0, min_share=0)      # every shape of this test takes the ping-pong kernel
+        ops.set_pp(grid=pp_grid, dmapos=pp_dma, min_steps=0, min_share=0)      # every shape of this test takes the ping-pong kernel (dmapos < 0: keep the default SCHED)
         try:
             O = torch.zeros(M * ldo, dtype=T, device='cuda')
             extra = None
@@ -275,13 +276,15 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
             out[tap] = (host(O).reshape(M, ldo), plan, extra)
         finally:
             ops.set_igemm_tap(2)
-            ops.set_pp(grid=0, dmapos=0, min_steps=18, min_share=12)
+            ops.set_pp(grid=0, min_steps=18, min_share=12)
     y0, y1 = out[0][0], out[1][0]
     assert np.all(y1[:, Cout:] == 0)
     assert_close(y1, y0, 8e-3, 'tap-fused vs per-tap %s %s' % (shape, epilogue))     # one bf16 ulp where the f32 sums round differently
     assert np.mean(y1 != y0) < 0.02
     if epilogue in ('plain', 'bias_leaky') and M * Cin * Cout <= 16 * 169 * 512 * 1024:
-        ref = R.conv2d(x, w).reshape(M, Cout)
+        if shape not in _TAP_ORACLE:
+            _TAP_ORACLE[shape] = R.conv2d(x, w).reshape(M, Cout)
+        ref = _TAP_ORACLE[shape]
         if epilogue == 'bias_leaky':
             ref = ref + host(bias)
             ref = np.maximum(ref, 0.1 * ref)

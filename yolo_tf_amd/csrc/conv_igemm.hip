@@ -1169,7 +1169,7 @@ static std::atomic<long> g_pp_min_steps{getenv("YOLO2_PP_MIN_STEPS") ? atol(gete
 static std::atomic<long> g_pp_min_share{getenv("YOLO2_PP_MIN_SHARE") ? atol(getenv("YOLO2_PP_MIN_SHARE")) : 12};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
     if (grid >= 0) g_pp_grid.store(grid, std::memory_order_relaxed);
-    if (dmapos >= 0) g_pp_dmapos.store(dmapos ? 1 : 0, std::memory_order_relaxed);
+    if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
     if (min_steps >= 0) g_pp_min_steps.store(min_steps, std::memory_order_relaxed);
     if (min_share >= 0) g_pp_min_share.store(min_share, std::memory_order_relaxed);
     return YOLO2_OK;

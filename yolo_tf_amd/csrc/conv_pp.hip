@@ -35,9 +35,30 @@
 #define Y2P_BBYTES (Y2P_BN * 128)
 #define Y2P_LOADS 3                        // DMA instructions per wave per K step: 1 halo slot + 2 filter pieces
 
-// HROWS = halo rows held (>= 256 + 2 W + 2, multiple of 8), NSB = filter ring depth (DMA runs NSB-1 steps ahead of the reads),
-// DMAPOS: 0 = a step's DMA pieces are issued at the head of its LOAD phase, 1 = behind the first four MFMAs of its MFMA phase
-template <bool BNBWD, int HROWS, int NSB, int DMAPOS>
+// DMA instructions in the slot of tap t (any integer: taps wrap around the nine of a chunk): halo piece (or its idle stand-in) + two filter pieces
+constexpr int y2p_slot_loads(int t, int hslots, bool skipidle) {
+    const int t9 = ((t % 9) + 9) % 9;
+    return (!skipidle || t9 < hslots) ? 3 : 2;
+}
+// How many of its newest DMA instructions a wave may leave in flight at the end of LOAD(tap tp) so that its pieces of the NEXT step have landed
+constexpr int y2p_leave(int order, int D, int tp, int hslots, bool skipidle) {
+    int n = 0;
+    if (order == 1) { for (int k = 1; k <= D - 2; ++k) n += y2p_slot_loads(tp - k, hslots, skipidle); }       // slots issued in MFMA(kt-1) .. MFMA(kt-D+2)
+    else if (order == 4) {      // filter pairs of LOAD(kt-D+2 .. kt) + the halo pieces of MFMA(kt-D+1 .. kt-1)
+        n = 2 * (D - 1);
+        for (int k = 1; k <= D - 1; ++k) n += y2p_slot_loads(tp - k, hslots, skipidle) - 2;
+    } else { for (int k = 0; k <= D - 2; ++k) n += y2p_slot_loads(tp - k, hslots, skipidle); }                  // slots issued in LOAD(kt) .. LOAD(kt-D+2)
+    return n;
+}
+
+// HROWS = halo rows held (>= 256 + 2 W + 2, multiple of 8), NSB = filter ring depth (DMA runs NSB-1 steps ahead of the reads).
+// SCHED (A/B of where a step's three DMA pieces are issued; bits 0-2 = order):
+//   0  DMA pieces, then the fragment reads                       1  all pieces behind the first four MFMAs of the MFMA phase
+//   2  fragment reads, then the pieces (issued under the reads' latency)      3  reads, lgkmcnt(0), then the pieces (read-free gap)
+//   4  reads + the two filter pieces in the LOAD phase, the halo piece behind the first four MFMAs
+//   +8  slots of taps >= HSLOTS carry no halo piece at all (2 instead of 3 instructions; the counted waits use the exact per-tap sums)
+//   +16 s_setprio 1 for the MFMA phase
+template <bool BNBWD, int HROWS, int NSB, int SCHED>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
@@ -46,8 +67,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     constexpr int BM = Y2P_BM, BN = Y2P_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
     constexpr int HBYTES = HROWS * 128, HB = HBYTES + 1024, RING = 2 * HB, D = NSB - 1;
     constexpr int HPIECES = HROWS / 8, HSLOTS = (HPIECES + NW - 1) / NW;
+    constexpr int ORDER = SCHED & 7;
+    constexpr bool SKIPIDLE = (SCHED & 8) != 0, PRIO = (SCHED & 16) != 0;
+    // timing ablations (wrong results by design; scripts/pp_sweep.py): +64 no MFMAs, +128 no fragment reads, +256 no DMA inside the K loop
+    constexpr bool A_NOMFMA = (SCHED & 64) != 0, A_NOREAD = (SCHED & 128) != 0, A_NODMA = (SCHED & 256) != 0;
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
-    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + 1 - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
+    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + (ORDER == 4 ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + NSB * Y2P_BBYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -70,7 +95,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
     const double rcp_hw = 1.0 / (double)(H * W);
     const float rcp_w = 1.0f / (float)W;
-    const int frow = lane & 31;
     unsigned char *const zero0 = smem + HBYTES;         // the zero KiB of halo buffer 0: also the sink of idle DMA slots (out-of-range DMA writes zeros)
     typedef __attribute__((address_space(3))) void *lds_void_ptr;
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
@@ -93,28 +117,33 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     }
     auto mem_chunk = [&](int c) { const int m = c + rot; return m >= nch ? m - nch : m; };      // logical chunk (0 <= c <= nch) -> chunk in memory
 
+    // per-segment copy of the lane id the compiler cannot see through: everything a segment precomputes per lane is recomputed from it,
+    // so no per-lane value of one segment (or of the kernel prologue) stays live across the epilogue of another
+    int lane_s = lane;
+    asm volatile("" : "+v"(lane_s));
+    const int frow_s = lane_s & 31;
     // both zero KiB (the previous segment's epilogue staged its tile image over them)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)zero0, 16, Y2_OOB, 0, 0, 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)(zero0 + HB), 16, Y2_OOB, 0, 0, 0);
 
     // halo DMA descriptor: slot j of this wave is piece j * 8 + wave = halo rows 8 * piece .. + 7.  Rows before pixel 0 wrap to offsets
     // >= 2^31 and rows past the last pixel lie beyond num_records: both read as zeros.  Source-side swizzle ((row >> 1) & 7).
-    const int hr0 = wave * 8 + (lane >> 3);
-    const unsigned h_voff0 = (unsigned)(m0 - (W + 1) + hr0) * (unsigned)ldp * 2u + (unsigned)(((lane & 7) ^ ((hr0 >> 1) & 7)) * 16);
+    const int hr0 = wave * 8 + (lane_s >> 3);
+    const unsigned h_voff0 = (unsigned)(m0 - (W + 1) + hr0) * (unsigned)ldp * 2u + (unsigned)(((lane_s & 7) ^ ((hr0 >> 1) & 7)) * 16);
     const unsigned h_stride = 64u * (unsigned)ldp * 2u;
     // filter DMA descriptor (two pieces per wave: rows r and r + 8; filters >= Nf lie beyond num_records)
-    const int br0 = wave * 16 + (lane >> 3);
+    const int br0 = wave * 16 + (lane_s >> 3);
     unsigned b_voff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int r = br0 + 8 * i;
-        b_voff[i] = (unsigned)(n0 + r) * (unsigned)(TAPS * Cp) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+        b_voff[i] = (unsigned)(n0 + r) * (unsigned)(TAPS * Cp) * 2u + (unsigned)(((lane_s & 7) ^ ((r >> 1) & 7)) * 16);
     }
-    // which of the nine taps of this lane's two fragment rows lie inside the image
+    // which of the nine taps of this lane_s's two fragment rows lie inside the image
     unsigned amask = 0;                                  // 9 bits per fragment row, row i at bit 16 * i
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + frow;
+        const int m = m0 + wm * (TM * 32) + i * 32 + frow_s;
         unsigned mask = 0;
         if (m < M) {
             const int HW = H * W;
@@ -141,7 +170,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     // ---- LDS read addresses.  A: one per (tap, fragment row), valid for the halo buffer of the current chunk parity; the 16-k group
     // kk is XORed in (bits 5-6 come from the swizzle term alone: every other summand is a multiple of 128).  B: one per 16-k group.
     const unsigned lds0 = y2_lds_addr(smem);
-    const unsigned hi16 = (unsigned)(lane >> 5) << 4;
+    const unsigned hi16 = (unsigned)(lane_s >> 5) << 4;
     const int c_first = kt_beg / TAPS;
     unsigned aaddr[TAPS][TM];
 #pragma unroll
@@ -150,29 +179,29 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         const unsigned toffb = (unsigned)(((W + 1) + dh * W + dw) * ROWB);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const unsigned hb = (unsigned)((wm * (TM * 32) + i * 32 + frow) * ROWB) + toffb;      // halo row * 128
+            const unsigned hb = (unsigned)((wm * (TM * 32) + i * 32 + frow_s) * ROWB) + toffb;      // halo row * 128
             const bool ok = ((amask >> (16 * i + tp)) & 1u) != 0u;
-            const unsigned sw = ((hb >> 4) & 0x70u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane's half of the k group
+            const unsigned sw = ((hb >> 4) & 0x70u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane_s's half of the k group
             // masked (pixel, tap): the buffer's zero KiB, at the same offset inside a 256-byte bank line as the real row
             aaddr[tp][i] = lds0 + (unsigned)((c_first & 1) * HB) + (ok ? hb : (unsigned)HBYTES + (hb & 0x80u)) + sw;
         }
     }
     unsigned baddr[4];
     {
-        const unsigned brow = lds0 + (unsigned)(RING + (wn * TN * 32 + frow) * ROWB);
-        const unsigned bx = hi16 ^ ((unsigned)((frow >> 1) & 7) << 4);
+        const unsigned brow = lds0 + (unsigned)(RING + (wn * TN * 32 + frow_s) * ROWB);
+        const unsigned bx = hi16 ^ ((unsigned)((frow_s >> 1) & 7) << 4);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) baddr[kk] = brow + (bx ^ (unsigned)(kk * 32));
     }
 
     // one DMA slot: halo piece `hs` of chunk `hc` (or an idle write into the zero KiB) + the filter tile of K step `kb` into ring stage `bstage`
-    auto issue_slot = [&](int hs, int hc, int hc_mem, bool hreal, int kb, unsigned offB, int bstage) {
-        {
-            const bool real = hreal && hs * NW + wave < HPIECES;
-            unsigned char *dst = real ? smem + (hc & 1) * HB + (hs * NW + wave) * 1024 : zero0;
-            const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)hc_mem * 128u : Y2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
-        }
+    auto issue_halo = [&](int hs, int hc, int hc_mem, bool hreal) {
+        const bool real = hreal && hs * NW + wave < HPIECES;
+        unsigned char *dst = real ? smem + (hc & 1) * HB + (hs * NW + wave) * 1024 : zero0;
+        const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)hc_mem * 128u : Y2_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
+    };
+    auto issue_filter = [&](int kb, unsigned offB, int bstage) {
         const bool breal = kb < kt_end;
         unsigned char *Bs = smem + RING + bstage * Y2P_BBYTES;
 #pragma unroll
@@ -202,8 +231,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             unsigned char *dst = real ? smem + ((c_first + 1) & 1) * HB + (j * NW + wave) * 1024 : zero0;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_first + 1) * 128u : Y2_OOB, 0, 0, 0);
         }
+        // (prologue slots always carry three instructions, filter pieces first: never fewer, never in a later position, than the counted
+        // waits of the first steps assume for the steady-state slots they stand in for)
 #pragma unroll
-        for (int d = 0; d < D; ++d) issue_slot(0, 0, 0, false, kt_beg + d, filt_off(kt_beg + d), d);
+        for (int d = 0; d < D; ++d) {
+            issue_filter(kt_beg + d, filt_off(kt_beg + d), d);
+            issue_halo(0, 0, 0, false);
+        }
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
     __builtin_amdgcn_s_barrier();
@@ -212,6 +246,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);
 
     bf16x8 fa[4][TM], fb[4][TN];
+    if (A_NOREAD) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { fa[kk][i][e] = (bf16)(float)(lane_s + e); fb[kk][i][e] = (bf16)(float)(lane_s - e); }
+    }
     int kt = kt_beg;                                     // the K step the next executed phase pair belongs to
     int stage_r = 0, stage_i = D;                        // ring stage read by step kt / filled by the DMA slot of step kt (= stage of step kt + D)
 
@@ -224,38 +266,55 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             constexpr int tp = decltype(tap_tag)::value;
             if (tp >= lo && tp < hi) {
                 constexpr int bt = (tp + D) % TAPS;
+                constexpr bool has_halo = !SKIPIDLE || tp < HSLOTS;       // does this tap's slot carry a halo instruction at all?
                 const unsigned offB = (unsigned)(((tp + D >= TAPS) ? mc1 : mc0) * TAPS * 64 + bt * 64) * 2u;
-                auto dma = [&]() { issue_slot(tp, c + 1, mc1, tp < HSLOTS && next_ok, kt + D, offB, stage_i); };
+                auto dma_filter = [&]() { if (!A_NODMA) issue_filter(kt + D, offB, stage_i); };
+                auto dma_halo = [&]() { if (has_halo && !A_NODMA) issue_halo(tp, c + 1, mc1, tp < HSLOTS && next_ok); };
+                // DMA instructions this wave may leave in flight at the end of LOAD(tp): everything issued after its pieces of step kt+1
+                constexpr int LEAVE = y2p_leave(ORDER, D, tp, HSLOTS, SKIPIDLE);
                 // ---- LOAD phase
-                if (DMAPOS == 0) dma();
+                if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
+                if (!A_NOREAD) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
-                    const unsigned bb = baddr[kk] + so;
+                        for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
+                        const unsigned bb = baddr[kk] + so;
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                        for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // this wave's pieces of step kt+1 have landed (the D-1 newest slots -- D-2 when this step's slot is issued later -- stay in flight)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMAPOS == 0 ? D - 1 : D - 2) * Y2P_LOADS) : "memory");
+                if (ORDER == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ORDER == 2 || ORDER == 3) { dma_halo(); dma_filter(); }
+                if (ORDER == 4) dma_filter();
+                __builtin_amdgcn_sched_barrier(0);
+                // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
+                if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (A_NOMFMA && !A_NOREAD) {        // (ablation: the fragments count as used)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(fa[kk][0]), "v"(fa[kk][1]), "v"(fb[kk][0]), "v"(fb[kk][1]));
+                }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- MFMA phase: registers only
+                if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-                    if (DMAPOS == 1 && kk == 0) {
+                        for (int j = 0; j < TN; ++j)
+                            if (!A_NOMFMA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                    if ((ORDER == 1 || ORDER == 4) && kk == 0) {
                         __builtin_amdgcn_sched_barrier(0);
-                        dma();
+                        if (ORDER == 1) { dma_halo(); dma_filter(); } else dma_halo();
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -281,11 +340,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     if (wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
     __builtin_amdgcn_sched_barrier(0);
 
+    // Everything below indexes by (lane_e, wave_e): copies the compiler cannot see through, so that none of the hand-off / epilogue
+    // address arithmetic is hoisted above the K loop (it was: 37 VGPRs of it spilled to scratch in the BN-backward variant, reloaded --
+    // behind a vmcnt(0) that drains the DMA ring -- in every chunk of the loop).
+    int lane_e = lane, wave_e = wave;
+    asm volatile("" : "+v"(lane_e), "+s"(wave_e));
+    const int wm_e = wave_e / WGN, wn_e = wave_e % WGN;
     // ---- stream-K hand-off (as in conv_igemm_kernel: the workgroup holding K step 0 of a tile owns it; a tail segment is parked)
     {
         constexpr int SLOT = BM * BN;
         const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
-        const unsigned slot_lane = (unsigned)(((size_t)wave * (TM * TN * 16 * 64) + (size_t)lane * 4) * sizeof(float));
+        const unsigned slot_lane = (unsigned)(((size_t)wave_e * (TM * TN * 16 * 64) + (size_t)lane_e * 4) * sizeof(float));
         if (kt_beg > 0) {
             const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
@@ -329,31 +394,31 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         }
     }
 
-    // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave LDS image, 16-byte stores), with the
+    // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave_e LDS image, 16-byte stores), with the
     // forward statistics or the producer layer's BN-backward sums taken from the rounded values
     {
         const bool stats = !BNBWD && bn_part != nullptr;
         const bool bstats = BNBWD && bn_part != nullptr;
-        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave row) pair
+        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave_e row) pair
         constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
         static_assert(NW * WROWS * WSTRIDE <= RING, "tile image fits the halo buffers");
         float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
         Vec16<T> yv[YG];
-        const int bz_nb = min(n0 + wn * TN * 32 + (lane % WCPR) * VEC, Nf - VEC);
+        const int bz_nb = min(n0 + wn_e * TN * 32 + (lane_e % WCPR) * VEC, Nf - VEC);
         auto bz_load_y = [&](int it0) {
 #pragma unroll
             for (int u = 0; u < YG; ++u) {
-                const int m = min(m0 + wm * WROWS + ((it0 + u) * 64 + lane) / WCPR, M - 1);
+                const int m = min(m0 + wm_e * WROWS + ((it0 + u) * 64 + lane_e) / WCPR, M - 1);
                 yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
             }
         };
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write zeros into ring stages / the zero KiB)
-        __syncthreads();                                      // every wave has finished reading the last step's operands
-        unsigned char *wreg = smem + wave * (WROWS * WSTRIDE);
+        __syncthreads();                                      // every wave_e has finished reading the last step's operands
+        unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
         const bool tail = m0 + BM > M;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+            const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
             const bool n_ok = n < Nf;
             const float bv = (bias && n_ok) ? bias[n] : 0.f;
             const float sh = (stats && n_ok) ? bn_shift[n] : 0.f;
@@ -362,12 +427,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                    const int row = i * 32 + 4 * (lane_e >> 5) + (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bv;
                     if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
                     const T o = (T)v;
-                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane & 31)) * 2) = o;
-                    if (stats && (!tail || m0 + wm * WROWS + row < M)) {
+                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane_e & 31)) * 2) = o;
+                    if (stats && (!tail || m0 + wm_e * WROWS + row < M)) {
                         const float d = (float)o - sh;
                         s1 += d;
                         s2 += d * d;
@@ -377,8 +442,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             if (stats) {
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32 && n_ok) {
-                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                if (lane_e < 32 && n_ok) {
+                    const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                     float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
                     if (stats_unique) { *p1 = s1; *p2 = s2; }
                     else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
@@ -401,27 +466,33 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
             }
         }
+        static_assert(NIT % YG == 0, "whole groups of y vectors");
+        // (groups of YG rows, NOT unrolled across groups: fully unrolled, the eight iterations' loads were all hoisted to the top and the
+        // BN-backward variant needed more than 256 registers)
+#pragma unroll 1
+        for (int g0 = 0; g0 < NIT; g0 += YG) {
+            if (bstats && g0) bz_load_y(g0);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int id = it * 64 + lane;
-            const int row = id / WCPR, ch = id % WCPR;
-            const int m = m0 + wm * WROWS + row;
-            const int n = n0 + wn * TN * 32 + ch * VEC;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
-            if (bstats && it && it % YG == 0) bz_load_y(it);
-            if (m < M && n < Nf) {
-                *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
-                if (bstats) {
-                    const Vec16<T> y = yv[it % YG];
-                    Vec16<T> d;
-                    d.v = __builtin_bit_cast(decltype(d.v), v);
+            for (int u = 0; u < YG; ++u) {
+                const int id = (g0 + u) * 64 + lane_e;
+                const int row = id / WCPR, ch = id % WCPR;
+                const int m = m0 + wm_e * WROWS + row;
+                const int n = n0 + wn_e * TN * 32 + ch * VEC;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
+                if (m < M && n < Nf) {
+                    *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+                    if (bstats) {
+                        const Vec16<T> y = yv[u];
+                        Vec16<T> d;
+                        d.v = __builtin_bit_cast(decltype(d.v), v);
 #pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float xh = (y.get(k) - cmu[k]) * cinv[k];
-                        const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
-                        const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
-                        ps[0][k] += g * xh;
-                        ps[1][k] += g;
+                        for (int k = 0; k < VEC; ++k) {
+                            const float xh = (y.get(k) - cmu[k]) * cinv[k];
+                            const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
+                            const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
+                            ps[0][k] += g * xh;
+                            ps[1][k] += g;
+                        }
                     }
                 }
             }
@@ -434,9 +505,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                     ps[0][k] += __shfl_xor(ps[0][k], off, 64);
                     ps[1][k] += __shfl_xor(ps[1][k], off, 64);
                 }
-            const int nb = n0 + wn * TN * 32 + lane * VEC;
-            if (lane < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+            const int nb = n0 + wn_e * TN * 32 + lane_e * VEC;
+            if (lane_e < WCPR && nb < Nf) {
+                const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                 float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -453,15 +524,34 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 // flat (tile, K step) space -- one per CU = stream-K; one per tile = whole tiles, no hand-off.
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int dmapos, hipStream_t st) {
-#define Y2P_LAUNCH(BWDv, HRv, NSBv, DPv)                                                                                                    \
-    conv3x3_pp_kernel<BWDv, HRv, NSBv, DPv><<<dim3(grid), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, hipStream_t st) {
+#define Y2P_LAUNCH(BWDv, HRv, NSBv, SCv)                                                                                                    \
+    conv3x3_pp_kernel<BWDv, HRv, NSBv, SCv><<<dim3(grid), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
                                                                         H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate)
-#define Y2P_LAUNCH_DP(BWDv, HRv, NSBv) do { if (dmapos) Y2P_LAUNCH(BWDv, HRv, NSBv, 1); else Y2P_LAUNCH(BWDv, HRv, NSBv, 0); } while (0)
-    if (W <= 27) { if (bz.Y) Y2P_LAUNCH_DP(true, 312, 5); else Y2P_LAUNCH_DP(false, 312, 5); }
-    else if (W <= 55) { if (bz.Y) Y2P_LAUNCH_DP(true, 368, 4); else Y2P_LAUNCH_DP(false, 368, 4); }
-    else return 1;
-#undef Y2P_LAUNCH_DP
+#define Y2P_CASE(SCv)                                                                                              \
+    case SCv:                                                                                                      \
+        if (W <= 27) { if (bwd) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(false, 312, 5, SCv); }             \
+        else { if (bwd) Y2P_LAUNCH(true, 368, 4, SCv); else Y2P_LAUNCH(false, 368, 4, SCv); }                     \
+        return 0;
+    if (W > 55) return 1;
+    const bool bwd = bz.Y != nullptr || (sched & 32) != 0;      // (+32, measurements only: the BN-backward instantiation without its sums)
+#define Y2P_ABL_CASE(SCv)                                                                                          \
+    case SCv:                                                                                                      \
+        if (W <= 27) Y2P_LAUNCH(false, 312, 5, SCv); else Y2P_LAUNCH(false, 368, 4, SCv);                          \
+        return 0;
+    if (sched >= 64) {
+        switch (sched) {
+            Y2P_ABL_CASE(2 + 64) Y2P_ABL_CASE(2 + 128) Y2P_ABL_CASE(2 + 256) Y2P_ABL_CASE(2 + 64 + 128) Y2P_ABL_CASE(2 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256)
+            Y2P_ABL_CASE(2 + 64 + 256)
+            default: return 1;
+        }
+    }
+#undef Y2P_ABL_CASE
+    switch (sched & 31) {
+        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(2) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(18) Y2P_CASE(26)
+        default: break;
+    }
+#undef Y2P_CASE
 #undef Y2P_LAUNCH
-    return 0;
+    return 1;
 }

@@ -22,4 +22,4 @@ struct Y2BnBwd {
 // conv_pp.hip: ping-pong tap-fused 3x3 kernel (bf16, 256 x 128 tile); returns non-zero when the image is too wide for its halo buffers
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int dmapos, hipStream_t st);
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, hipStream_t st);
