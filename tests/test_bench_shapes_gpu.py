@@ -121,7 +121,9 @@ def test_forward_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
         # the launches that carry the benchmark: tap-fused 256x128 stream-K, one workgroup per CU ('stages' 9 = nine taps per halo image)
         assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8 and plan['stages'] == TAP_STAGES, plan
     if name == 'conv13_15_17' and B == 16:
-        assert plan['split'] == 2 and (plan['BM'], plan['stages']) == ((256, 18) if TAP_STAGES == 18 else (128, 3)), plan      # 88 / 176 tiles for 256 CUs: stream-K
+        assert plan['split'] == 2 and plan['BM'] == 128, plan      # 176 tiles for 256 CUs, 24.75 K steps per workgroup: stream-K on the per-tap 128x128 tile
+    if name == 'conv8_10_12' and B == 16 and TAP_STAGES == 18:
+        assert (plan['BM'], plan['stages'], plan['grid_x']) == (256, 18, 172), plan      # ping-pong kernel, one workgroup per tile (67 % of the CUs), no hand-off
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', [c for c in _cases() if c.values[2] != 'conv0'])
@@ -142,6 +144,8 @@ def test_dgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     check_act(got[..., :cin], R.conv2d_dgrad(dy, w), 'dgrad %s %s' % (cname, name))
     if name in ('conv18_19', 'conv20') and B == 16:
         assert plan['BM'] == 256 and plan['split'] == 2 and plan['stages'] == TAP_STAGES, plan
+    if name == 'conv5_7' and B == 16 and TAP_STAGES == 18:
+        assert (plan['BM'], plan['stages'], plan['grid_x']) == (256, 18, 169), plan      # 52x52 data gradient: 169 whole tiles
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', list(_cases()))

@@ -1164,11 +1164,11 @@ extern "C" int yolo2_debug_set_igemm_tap(int mode) {
 // ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
 // dmapos 0/1 = DMA pieces at the head of the LOAD phase / inside the MFMA phase; min_steps, min_share = the launch gates below (< 0: keep)
 static std::atomic<int> g_pp_grid{getenv("YOLO2_PP_GRID") ? atoi(getenv("YOLO2_PP_GRID")) : 0};
-static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_DMAPOS") ? atoi(getenv("YOLO2_PP_DMAPOS")) : 0};
+static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_SCHED") ? atoi(getenv("YOLO2_PP_SCHED")) : 2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
 static std::atomic<long> g_pp_min_steps{getenv("YOLO2_PP_MIN_STEPS") ? atol(getenv("YOLO2_PP_MIN_STEPS")) : 18};
-static std::atomic<long> g_pp_min_share{getenv("YOLO2_PP_MIN_SHARE") ? atol(getenv("YOLO2_PP_MIN_SHARE")) : 12};
+static std::atomic<long> g_pp_min_share{getenv("YOLO2_PP_MIN_SHARE") ? atol(getenv("YOLO2_PP_MIN_SHARE")) : 26};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
-    if (grid >= 0) g_pp_grid.store(grid, std::memory_order_relaxed);
+    if (grid != -1) g_pp_grid.store(grid, std::memory_order_relaxed);
     if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
     if (min_steps >= 0) g_pp_min_steps.store(min_steps, std::memory_order_relaxed);
     if (min_share >= 0) g_pp_min_share.store(min_share, std::memory_order_relaxed);
@@ -1227,9 +1227,15 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     if constexpr (std::is_same<T, bf16>::value) {
         const int tap_mode = g_igemm_tap.load(std::memory_order_relaxed);
         const int tap_on = tap_mode == 1;
-        // Ping-pong tap-fused kernel (conv_pp.hip): every 3x3 layer on images up to 55 wide whose input is a multiple of 64 channels.
-        // Stream-K over one workgroup per CU when a workgroup's share of the flat (tile, K step) space amortises its hand-offs;
-        // one workgroup per tile otherwise.
+        // Ping-pong tap-fused kernel (conv_pp.hip): 3x3 layers on images up to 55 wide whose input is a multiple of 64 channels.  Its
+        // fixed cost per launch (~24 us: prologue, stream-K hand-off, epilogue) against ~0.65 us per K step decides where it wins
+        // (profiles/r04_pp2_*.txt, r04_pp3_*.txt, batch 16 and 8):
+        //   * a tile grid that gives 60-100 % of the CUs one whole tile each: one workgroup per tile, no hand-off (26x26 256->512 forward
+        //     30.8 vs 35.1 us; 52x52 data gradients 31 vs 36.5 us);
+        //   * else stream-K over one workgroup per CU when a workgroup's share is >= 26 K steps (the >= 1024-channel 13x13 layers:
+        //     56 vs 60 us, 129 vs 144 us; the 512-channel ones, 24.75 steps per workgroup, stay with the per-tap kernels);
+        //   * a data gradient that also reduces the producer's BN-backward sums takes it from 10 steps per workgroup when it has >= 8192
+        //     pixels: the per-tap kernels' form of that epilogue costs 12-30 us there, this one 4-7.
         if (tap_mode == 2 && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream &&
             (long)9 * (Cp / 64) >= g_pp_min_steps.load(std::memory_order_relaxed) && tu.cus <= Y2_STREAM_FLAG_WORDS) {
             const long tiles_t = (long)MT2 * NT2, units_p = tiles_t * 9 * (Cp / 64);
@@ -1238,8 +1244,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             int grid = 0;
             if (gm == 1) grid = can_stream ? tu.cus : 0;
             else if (gm == 2) grid = tiles_t <= Y2_STREAM_FLAG_WORDS ? (int)tiles_t : 0;
-            else if (can_stream && units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus) grid = tu.cus;
-            else if (tiles_t >= tu.cus / 2 && tiles_t <= Y2_STREAM_FLAG_WORDS) grid = (int)tiles_t;
+            else if (gm >= 8) grid = (can_stream && gm <= tu.cus) ? gm : 0;                  // explicit workgroup count (sweeps)
+            else if (gm <= -2) grid = (can_stream && tiles_t * -gm <= tu.cus) ? (int)(tiles_t * -gm) : 0;      // -P: every tile cut into exactly P shares
+            else if (tiles_t * 10 >= (long)tu.cus * 6 && tiles_t <= tu.cus) grid = (int)tiles_t;
+            else if (can_stream && (units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus || (bz.Y && M >= 8192 && units_p >= 10L * tu.cus))) grid = tu.cus;
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];

@@ -56,6 +56,8 @@ constexpr int y2p_leave(int order, int D, int tp, int hslots, bool skipidle) {
 //   0  DMA pieces, then the fragment reads                       1  all pieces behind the first four MFMAs of the MFMA phase
 //   2  fragment reads, then the pieces (issued under the reads' latency)      3  reads, lgkmcnt(0), then the pieces (read-free gap)
 //   4  reads + the two filter pieces in the LOAD phase, the halo piece behind the first four MFMAs
+//   5  as 2, but the pixel (A) fragments of step s+1 are read behind the MFMAs of step s, each 16-k group into the registers its four
+//      MFMAs have just released: the LOAD phase keeps the eight filter reads + the pieces and becomes shorter than the MFMA phase
 //   +8  slots of taps >= HSLOTS carry no halo piece at all (2 instead of 3 instructions; the counted waits use the exact per-tap sums)
 //   +16 s_setprio 1 for the MFMA phase
 template <bool BNBWD, int HROWS, int NSB, int SCHED>
@@ -72,7 +74,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     // timing ablations (wrong results by design; scripts/pp_sweep.py): +64 no MFMAs, +128 no fragment reads, +256 no DMA inside the K loop
     constexpr bool A_NOMFMA = (SCHED & 64) != 0, A_NOREAD = (SCHED & 128) != 0, A_NODMA = (SCHED & 256) != 0;
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
-    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + (ORDER == 4 ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
+    // (ORDER 4 issues the halo piece half a step later; ORDER 5 reads the next chunk's halo one step earlier: one slot less each)
+    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + ((ORDER == 4 || ORDER == 5) ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + NSB * Y2P_BBYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -276,10 +279,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
                 if (!A_NOREAD) {
+                    // ORDER 5: the pixel fragments of this step were read behind the MFMAs of the previous one (below) -- except for the
+                    // first step of a segment; the LOAD phase then carries the eight filter fragment reads only
+                    if (ORDER != 5 || kt == kt_beg) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
                         const unsigned bb = baddr[kk] + so;
 #pragma unroll
                         for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
@@ -287,12 +296,15 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ORDER == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ORDER == 2 || ORDER == 3) { dma_halo(); dma_filter(); }
+                if (ORDER == 2 || ORDER == 3 || ORDER == 5) { dma_halo(); dma_filter(); }
                 if (ORDER == 4) dma_filter();
                 __builtin_amdgcn_sched_barrier(0);
                 // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
                 if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // lgkmcnt(0) through the builtin, not asm: hipcc's own wait insertion must KNOW that every fragment read has returned here, or
+                // it counts the LOAD-phase reads as still outstanding and puts lgkmcnt(3) / lgkmcnt(1) in front of the later MFMA groups --
+                // which then wait for the ORDER-5 prefetch reads issued a few instructions earlier (gfx9 encoding: vmcnt 63, expcnt 7, lgkmcnt 0)
+                __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (A_NOMFMA && !A_NOREAD) {        // (ablation: the fragments count as used)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(fa[kk][0]), "v"(fa[kk][1]), "v"(fb[kk][0]), "v"(fb[kk][1]));
@@ -301,6 +313,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- MFMA phase: registers only
                 if (PRIO) __builtin_amdgcn_s_setprio(1);
+                const bool pre_a = ORDER == 5 && !A_NOREAD && kt + 1 < kt_end;       // a next step exists in this segment: fetch its pixel fragments here
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -311,6 +324,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                     if ((ORDER == 1 || ORDER == 4) && kk == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (ORDER == 1) { dma_halo(); dma_filter(); } else dma_halo();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (ORDER == 5) {
+                        // the four MFMAs above were the last readers of fa[kk]: refill it with the NEXT step's 16-k group (tap tp+1; tap 0 of the
+                        // next chunk after tap 8: its addresses already point at the other halo buffer, whose pieces every wave waited for by the
+                        // end of LOAD(tap 7)).  The reads return during the next LOAD phase, whose lgkmcnt(0) covers them.
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (pre_a) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[(tp + 1) % TAPS][i] ^ (unsigned)(kk * 32));
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -535,20 +559,26 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         return 0;
     if (W > 55) return 1;
     const bool bwd = bz.Y != nullptr || (sched & 32) != 0;      // (+32, measurements only: the BN-backward instantiation without its sums)
+#ifdef Y2P_EXPERIMENTS      // (scripts/pp_experiments_build.sh: the SCHED variants and timing ablations behind profiles/r04_pp*.txt)
 #define Y2P_ABL_CASE(SCv)                                                                                          \
     case SCv:                                                                                                      \
         if (W <= 27) Y2P_LAUNCH(false, 312, 5, SCv); else Y2P_LAUNCH(false, 368, 4, SCv);                          \
         return 0;
     if (sched >= 64) {
         switch (sched) {
-            Y2P_ABL_CASE(2 + 64) Y2P_ABL_CASE(2 + 128) Y2P_ABL_CASE(2 + 256) Y2P_ABL_CASE(2 + 64 + 128) Y2P_ABL_CASE(2 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256)
-            Y2P_ABL_CASE(2 + 64 + 256)
+            Y2P_ABL_CASE(5 + 64) Y2P_ABL_CASE(5 + 128) Y2P_ABL_CASE(5 + 256) Y2P_ABL_CASE(5 + 64 + 128) Y2P_ABL_CASE(5 + 128 + 256) Y2P_ABL_CASE(5 + 64 + 128 + 256)
+            Y2P_ABL_CASE(5 + 64 + 256)
             default: return 1;
         }
     }
 #undef Y2P_ABL_CASE
     switch (sched & 31) {
-        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(2) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(18) Y2P_CASE(26)
+        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(5) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(13) Y2P_CASE(18) Y2P_CASE(26)
+        default: break;
+    }
+#endif
+    switch (sched & 31) {
+        Y2P_CASE(2)
         default: break;
     }
 #undef Y2P_CASE
