@@ -1,5 +1,5 @@
 """Per-layer A/B of the 3x3 implicit-GEMM variants on the Darknet-19 shapes (bf16): per-tap kernels (mode 0), the round-2 tap-fused kernel
-where its gates admit it (mode 1) and the ping-pong kernel (mode 2) as stream-K / one workgroup per tile with its SCHED variants
+(mode 1: until commit 2e72607+3; gone since) and the ping-pong kernel (mode 2) as stream-K / one workgroup per tile with its SCHED variants
 (conv_pp.hip).  Every configuration's outputs are also compared with the per-tap kernels' on the same operands (max |diff| / max |ref|).
 usage: B=16 [LAYERS=conv8,conv20] [CONFIGS=name:mode:grid:sched,...] python scripts/pp_sweep.py   -> us | TFLOP/s per launch, one box, hipGraph-replayed."""
 import os, sys
@@ -12,7 +12,7 @@ if os.environ.get('LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['LAYERS'].split(',')]
 B = int(os.environ.get('B', 16))
 T = torch.bfloat16
-CONFIGS = [('per-tap', 0, 0, 0), ('tap-r2', 1, 0, 0), ('pp-sk', 2, 1, -1), ('pp-tile', 2, 2, -1)]      # sched -1 = the library default
+CONFIGS = [('per-tap', 0, 0, 0), ('pp-rule', 2, 0, 2), ('pp-sk', 2, 1, 2), ('pp-tile', 2, 2, 2)]
 if os.environ.get('CONFIGS'):
     CONFIGS = [(c.split(':')[0],) + tuple(int(v) for v in c.split(':')[1:]) for c in os.environ['CONFIGS'].split(',')]
 WHAT = os.environ.get('WHAT', 'fwd+stats,dgrad,dgrad+bn').split(',')

@@ -304,6 +304,21 @@ def make_topology(ref_inf2, ref_inf1):
         consts = {k: list(getattr(ref_inf1 if key == 'yolo_tiny' else ref_inf2, k)) for k in dir(ref_inf1 if key == 'yolo_tiny' else ref_inf2) if k.endswith('_DOWNSAMPLING')}
         entry['downsampling'] = consts
         topo[key] = entry
+    # Training-mode (batch statistics) logits on 128x128 images: 2 x 4 x 4 = 32 samples per channel in the 1/32 stages, 128 at 1/16, ...
+    # (the 64x64 case above leaves 8 there, where a batch variance is mostly noise); COCO-80 head; and `_darknet` -- the
+    # biases-instead-of-beta branch (model/yolo2/inference.py:122-126 calls darknet(..., center=False))
+    for key, base, fn, classes, size in (('yolo2_darknet_t128', 'yolo2_darknet', ref_inf2.darknet, 20, 128), ('yolo2_darknet_coco_t128', 'yolo2_darknet_coco', ref_inf2.darknet, 80, 128),
+                                         ('yolo2__darknet_t128', 'yolo2__darknet', ref_inf2._darknet, 20, 128)):
+        rng = np.random.RandomState(62)
+        image = rng.standard_normal((2, size, size, 3)).astype(np.float32)
+        shim.reset(lambda name, shape, kind: seeded.value(name, shape, kind))
+        scope, net = fn(tf.constant(image), classes, 5, training=True)
+        cases[key + '/image'] = image
+        cases[key + '/train/logits'] = net.value
+        names = sorted(shim.UPDATES)
+        for n in (names[0], names[1], names[-2], names[-1]):
+            cases[key + '/train/update/' + n] = shim.UPDATES[n]
+        topo[key] = {'base': base, 'function': fn.__name__, 'classes': classes, 'boxes': 5, 'input': [2, size, size, 3], 'scope': scope}
     with open(os.path.join(OUT, 'topology.json'), 'w') as f:
         json.dump(topo, f, indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(OUT, 'network.npz'), **cases)

@@ -19,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-TAP_STAGES = {'0': 3, '1': 9, '2': 18}[os.environ.get('YOLO2_IGEMM_TAP', '2')]      # plan word 'stages' of the kernel that takes the 13x13 layers: ping-pong tap-fused (default), round-2 tap-fused, per-tap stream-K
+TAP_STAGES = 3 if os.environ.get('YOLO2_IGEMM_TAP', '2') == '0' else 18      # plan word 'stages' of the kernel that takes the 13x13 layers: ping-pong tap-fused (default) / per-tap stream-K (A/B)
 
 from oracle import yolo2_ref as R
 

@@ -204,7 +204,7 @@ TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 
               (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256),
               (3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
 # variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong SCHED (-1 = the default))
-TAP_VARIANTS = {'tap': (1, 0, -1), 'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1)}
+TAP_VARIANTS = {'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1)}
 _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant and epilogue: minutes of CPU time when recomputed 12 times)
 
 
@@ -212,9 +212,9 @@ _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant
 @pytest.mark.parametrize('variant', list(TAP_VARIANTS))
 @pytest.mark.parametrize('shape', TAP_SHAPES)
 def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
-    """The tap-fused 3x3 kernels (one halo image per 64-channel chunk, nine taps read from it: conv3x3_tap_kernel of round 2 and the
-    ping-pong conv3x3_pp_kernel, as stream-K and with one workgroup per tile) against the per-tap kernel on the same operands -- same
-    products, a different f32 summation order across stream-K segments only -- and against the oracle."""
+    """The ping-pong tap-fused 3x3 kernel (conv_pp.hip: one halo image per 64-channel chunk, nine taps read from it), as stream-K and with
+    one workgroup per tile, against the per-tap kernel on the same operands -- same products, a different f32 summation order across
+    stream-K segments only -- and against the oracle."""
     B, H, W, Cin, Cout = shape
     mode, pp_grid, pp_dma = TAP_VARIANTS[variant]
     k, M = 3, B * H * W
@@ -230,7 +230,7 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
     bias = dev(rng.randn(Cout).astype(np.float32))
     out = {}
     for tap in (0, 1):
-        ops.set_igemm_tap(mode if tap else 0)     # (the round-2 kernel: run with YOLO2_IGEMM_TAP_MIN_STEPS=0 YOLO2_IGEMM_TAP_MIN_SHARE=12 to force the short reductions through it too)
+        ops.set_igemm_tap(mode if tap else 0)
         ops.set_pp(grid=pp_grid, dmapos=pp_dma, min_steps=0, min_share=0)      # every shape of this test takes the ping-pong kernel (dmapos < 0: keep the default SCHED)
         try:
             O = torch.zeros(M * ldo, dtype=T, device='cuda')
@@ -265,14 +265,9 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
                 extra = (dg, db, part, None, yprev, pm, pv, pg, pb)
             plan = ops.last_conv_plan()
             torch.cuda.synchronize()
-            if mode == 1:
-                takes_tap = tap and (9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_STEPS', 144))
-                                     and -(-M // 256) * -(-Cout // 128) * 9 * (Cin // 64) >= int(os.environ.get('YOLO2_IGEMM_TAP_MIN_SHARE', 40)) * 256)
-                assert (plan['stages'] == 9) == bool(takes_tap), plan
-            else:
-                assert (plan['stages'] == 18) == bool(tap and Cout > 64), plan
-                if tap and pp_grid == 2:
-                    assert plan['grid_x'] == -(-M // 256) * -(-Cout // 128), plan
+            assert (plan['stages'] == 18) == bool(tap and Cout > 64), plan
+            if tap and pp_grid == 2:
+                assert plan['grid_x'] == -(-M // 256) * -(-Cout // 128), plan
             out[tap] = (host(O).reshape(M, ldo), plan, extra)
         finally:
             ops.set_igemm_tap(2)

@@ -20,11 +20,12 @@ HP = {'prob': 1., 'iou_best': 5., 'iou_normal': 1., 'coords': 1.}
 def make_builder(inference, names, size, training, basedir):
     from yolo_tf_amd import utils
     from yolo_tf_amd.model import yolo2
-    cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo2', '%s-%d.ini' % (inference, names))], basedir)
+    cfg = utils.make_config([os.path.join(ROOT, 'config.ini'), os.path.join(ROOT, 'config', 'yolo2', '%s-%d.ini' % (inference.strip('_'), names))], basedir)
     cfg.set('cache', 'names', os.path.join(ROOT, cfg.get('cache', 'names')))
     cfg.set('yolo2', 'anchors', os.path.join(ROOT, cfg.get('yolo2', 'anchors')))
     cfg.set('yolo2', 'width', str(size))
     cfg.set('yolo2', 'height', str(size))
+    cfg.set('yolo2', 'inference', inference)        # (`_darknet` / `_tiny`: the biases-instead-of-beta plugins share their base's overlay)
     utils.ensure_names(cfg)
     b = yolo2.Builder(None, cfg)
     b(None, training=training)

@@ -559,440 +559,6 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Tap-fused 3x3 implicit GEMM (bf16, 256 x 128 tile, 8 waves of 64 x 64, stream-K).
-//
-// The kernel above DMAs the pixel operand once per TAP: nine shifted copies of the same 64-channel slab per chunk, and the
-// L2 -> LDS path (~15 TB/s chip-wide, profiles/r02_igemm_analysis.md) is what bounds it.  In NHWC the 3x3 neighbourhood of the
-// 256 consecutive pixels m0..m0+255 is the CONTIGUOUS pixel range m0-(W+1) .. m0+255+(W+1): tap (dh, dw) of pixel m is flattened
-// pixel m + dh*W + dw.  So one "halo" image of 256 + 2W + 2 pixel rows x 64 channels per chunk serves all nine taps; the A fragment
-// of tap t is read from LDS row (pixel row + (W+1) + dh*W + dw), and a lane whose (pixel, tap) falls outside the image reads a
-// zero chunk instead (9-bit mask per fragment row, as before).  Operand DMA per 64-channel chunk: halo 46 KiB + 9 filter tiles
-// of 16 KiB = 190 KiB, against 9 x 48 KiB = 432 KiB for the 256 x 128 tile above (and 9 x 64 KiB per 256 pixels for the 128 x 128 one).
-//
-// LDS: two halo buffers (chunk c is read while chunk c+1 lands, one 1 KiB piece per wave per K step), a 3-deep ring of filter
-// tiles, and 1 KiB that only ever receives out-of-range DMA (always zero: the source of masked fragments, the sink of idle slots).
-// Every wave issues exactly Y2T_LOADS DMA instructions per K step, so "filter tile kt has landed" is vmcnt(Y2T_LOADS) at every
-// step; halo pieces are older than the filter tile of their first use by construction (issued in slots 0..5 of the previous
-// chunk, the filter tile of (c+1, tap 0) in slot 7).
-#define Y2T_BM 256
-#define Y2T_BN 128
-#define Y2T_BBYTES (Y2T_BN * 128)
-#define Y2T_DMA_EARLY 0
-#define Y2T_LOADS 3                        // per wave per K step: 1 halo slot + 2 filter pieces
-// HROWS = halo rows held (>= 256 + 2 W + 2), NSB = filter ring depth: (368, 4) for images up to 55 wide; (312, 5) up to 27 wide,
-// whose smaller halo buys a fifth ring stage = DMA four steps ahead of the MFMAs instead of three (160 KiB of LDS either way)
-template <bool BNBWD, int HROWS, int NSB>
-__global__ __launch_bounds__(512) void conv3x3_tap_kernel(
-    const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
-    bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate) {
-    typedef bf16 T;
-    constexpr int BM = Y2T_BM, BN = Y2T_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
-    constexpr int HBYTES = HROWS * 128, ZERO = 2 * HBYTES + NSB * Y2T_BBYTES, HPIECES = HROWS / 8, HSLOTS = (HPIECES + NW - 1) / NW;
-    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS - NSB + 1 && ZERO + 1024 <= 160 * 1024, "halo pieces fit the slots that are older than the next chunk's first filter tile");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[ZERO + 1024];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int MT = (M + BM - 1) / BM;
-    const int nk = (Cp / 64) * TAPS;                     // K steps per tile: (64-channel chunk, tap)
-    const long su_total = (long)MT * NT * nk;
-    const int G = gridDim.x;
-    const int wx = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-    long su = wx * su_total / G;
-    const long su_end = (wx + 1) * su_total / G;
-    // K rotation (round 3).  A tile's K steps are shared by P ~ nk / share consecutive workgroups, and the workgroups of an XCD all work
-    // on the same filter tile's slab (BN x K: 7 MB on the 3072-channel layer, more than the 4 MB L2).  With every tile starting at K
-    // step 0, the j-th workgroup enters its tile at offset (j * share) mod nk, which drifts by P * share - nk per tile: the ~32
-    // workgroups of an XCD sit at ~32 different K positions and each of the 11 pixel tiles re-streams the slab from the fabric
-    // (814 MB fetched for 79 MB of operands, profiles/r02_hbm_traffic_pmc.md row 70).  The sum over K does not care where it starts:
-    // tile t processes its chunks in the cyclic order (c + rot_t) mod nch with rot_t cancelling the drift, so the workgroups holding the
-    // first / second / third share of their tiles all read the same slab bytes at the same time and the L2 serves all but one of them.
-    // Ownership, parking and the flat (tile, step) bookkeeping are untouched: only the chunk -> memory offset mapping rotates.
-    const int nch = Cp / 64;
-    const double share = (double)su_total / (double)G;
-    const int shares_per_tile = (int)((double)nk / share + 0.5);
-    const double drift_chunks = k_rotate && shares_per_tile >= 2 ? ((double)shares_per_tile * share - (double)nk) / (double)TAPS : 0.0;
-
-    const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(P), 0, p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
-    const double rcp_hw = 1.0 / (double)(H * W);
-    const float rcp_w = 1.0f / (float)W;
-    const int hneed = BM + 2 * W + 2;                    // halo rows that exist for this image width
-    const int frow = lane & 31;
-    unsigned char *const zero = smem + ZERO;
-    // the zero KiB: written by out-of-range DMA only (first here, then by every idle slot)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)zero, 16, Y2_OOB, 0, 0, 0);
-
-  for (bool first_seg = true;; first_seg = false) {
-    if (su >= su_end) break;
-    const int t = (int)(su / nk);
-    const int kt_beg = (int)(su - (long)t * nk);
-    const int kt_end = (int)min((long)nk, kt_beg + (su_end - su));
-    su += kt_end - kt_beg;
-    const int nt = t / MT, mt = t - nt * MT;
-    if (!first_seg) __syncthreads();                     // every wave is done with the previous segment's LDS
-    const int m0 = mt * BM, n0 = nt * BN;
-    int rot;                                             // this tile's chunk rotation, 0 <= rot < nch
-    {
-        const long r = (long)__builtin_floor(-(double)t * drift_chunks + 0.5);
-        rot = (int)(r % nch);
-        if (rot < 0) rot += nch;
-        rot = __builtin_amdgcn_readfirstlane(rot);
-    }
-    auto mem_chunk = [&](int c) { const int m = c + rot; return m >= nch ? m - nch : m; };      // logical chunk (0 <= c <= nch) -> chunk in memory
-
-    // halo DMA descriptor: slot j of this wave is piece j * 8 + wave = halo rows 8 * piece .. + 7 (pieces >= HPIECES do not exist).  Rows
-    // before pixel 0 wrap to offsets >= 2^31 and rows past the last pixel lie beyond num_records: both read as zeros; slot j is slot
-    // 0 plus 64 pixel rows (the source-side swizzle ((row >> 1) & 7) does not depend on j).
-    const int hr0 = wave * 8 + (lane >> 3);
-    const unsigned h_voff0 = (unsigned)(m0 - (W + 1) + hr0) * (unsigned)ldp * 2u + (unsigned)(((lane & 7) ^ ((hr0 >> 1) & 7)) * 16);
-    const unsigned h_stride = 64u * (unsigned)ldp * 2u;
-    // filter DMA descriptor (two pieces per wave: rows r and r + 8; filters >= Nf lie beyond num_records)
-    const int br0 = wave * 16 + (lane >> 3);
-    unsigned b_voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = br0 + 8 * i;
-        b_voff[i] = (unsigned)(n0 + r) * (unsigned)(TAPS * Cp) * 2u + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-    }
-    // the fragment rows this lane feeds to the MFMA and which of their nine taps lie inside the image
-    unsigned amask = 0;                                  // 9 bits per fragment row (TM = 2 rows per lane)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + frow;
-        unsigned mask = 0;
-        if (m < M) {
-            const int HW = H * W;
-            int bq = (int)((double)m * rcp_hw);
-            int rem = m - bq * HW;
-            if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
-            int h = (int)((float)rem * rcp_w);
-            int w = rem - h * W;
-            if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
-            const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
-            mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
-        }
-        amask |= mask << (16 * i);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // one DMA slot: halo piece `hs` of chunk `hc` (or an idle write into the zero KiB) + the filter tile of K step `kb`
-    auto issue_slot = [&](int hs, int hc, int kb, int bstage) {
-        {
-            const bool real = hs >= 0 && hs < HSLOTS && hs * NW + wave < HPIECES && hc * TAPS < kt_end;
-            unsigned char *dst = real ? smem + (hc & 1) * HBYTES + (hs * NW + wave) * 1024 : zero;
-            const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)mem_chunk(hc) * 128u : Y2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
-        }
-        const bool breal = kb < kt_end;
-        const int bc = kb / TAPS, bt = kb - bc * TAPS;
-        const unsigned offB = (unsigned)(mem_chunk(bc) * TAPS * 64 + bt * 64) * 2u;
-        unsigned char *Bs = smem + 2 * HBYTES + bstage * Y2T_BBYTES;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned char *dst = Bs + (wave * 2 + i) * 1024;             // (an idle slot zero-fills a stage no valid step reads any more)
-            const unsigned voff = breal ? b_voff[i] + offB : Y2_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (__attribute__((address_space(3))) void *)dst, 16, voff, 0, 0, 0);
-        }
-    };
-
-    // ---- software-pipelined K loop.  Step k's MFMAs run on fragment registers read during step k-1; while they execute, the same wave
-    // reads step k+1's fragments into the other register set (one ds_read per MFMA, pinned with sched_group_barrier).  A first
-    // version that did address arithmetic -> 16 reads -> 16 MFMAs in sequence spent a third of each step in each (timing ablations,
-    // profiles/r02_igemm_tap.md: MFMA time, read time and ~150 VALU of per-step addressing simply ADDED UP, both waves of a SIMD
-    // being in the same phase between barriers).  Per step and wave now: ~40 VALU, 3 DMA, 16 ds_read, 16 MFMA.
-    // DMA runs three steps ahead (4-deep filter ring): at the top of step k everything but the newest slot has landed = the
-    // operands of steps k and k+1.
-    const unsigned lds0 = y2_lds_addr(smem);
-    unsigned rowb[TM];                                   // byte offset of this lane's fragment rows in halo space (tap (0,0) adds toff)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) rowb[i] = (unsigned)((wm * (TM * 32) + i * 32 + frow) * ROWB);
-    const unsigned hi16 = (unsigned)(lane >> 5) << 4;
-    const unsigned brow = lds0 + (unsigned)(2 * HBYTES + (wn * TN * 32 + frow) * ROWB);      // this lane's filter fragment row in ring stage 0
-    const unsigned bx = hi16 ^ ((unsigned)((frow >> 1) & 7) << 4);
-    typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
-    // LDS addresses of one K step's fragment reads: two halo rows (or the zero chunk) + the swizzle term, and the filter ring stage
-    struct FragAddr { unsigned abase[TM], ax[TM], bbase; };
-    auto calc_addr = [&](FragAddr &fa_, int ck, int tp, int bs) {
-        const int dh = tp / 3 - 1, dw = tp - (tp / 3) * 3 - 1;
-        const unsigned toffb = (unsigned)(((W + 1) + dh * W + dw) * ROWB);
-        const unsigned hbase = lds0 + (unsigned)((ck & 1) * HBYTES);
-        const unsigned tbit = 1u << tp;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned hb = rowb[i] + toffb;                      // halo row * 128
-            const bool ok = (amask & (tbit << (16 * i))) != 0u;
-            // masked (pixel, tap): the zero KiB, at the SAME offset inside a 256-byte bank line as the real row (one fixed zero chunk
-            // for every masked lane collided with the other lanes' banks: SQ_LDS_BANK_CONFLICT 19 % of the LDS cycles on 13x13 images)
-            fa_.abase[i] = ok ? hb + hbase : lds0 + (unsigned)ZERO + (hb & 0x80u);
-            fa_.ax[i] = ((hb >> 4) & 0x70u) ^ hi16;                   // ((row >> 1) & 7) << 4, folded with this lane's half of the k group
-        }
-        fa_.bbase = brow + (unsigned)(bs * Y2T_BBYTES);
-    };
-    auto read_frags = [&](bf16x8 (&fa)[4][TM], bf16x8 (&fb)[4][TN], const FragAddr &ad) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(ad.abase[i] + (ad.ax[i] ^ (unsigned)(kk * 32)));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(ad.bbase + (bx ^ (unsigned)(kk * 32)) + (unsigned)(j * 32 * ROWB));
-        }
-    };
-    auto next_step = [&](int &ck, int &tp) { if (++tp == TAPS) { tp = 0; ++ck; } };
-
-    int c_chunk = kt_beg / TAPS, c_tap = kt_beg - (kt_beg / TAPS) * TAPS;
-    {   // prologue: the whole halo of the first chunk (+ the pieces of the next chunk whose slots this segment starts behind),
-        // then filter tiles kt_beg .. kt_beg + 2
-#pragma unroll
-        for (int j = 0; j < HSLOTS; ++j) {
-            const bool real = j * NW + wave < HPIECES;
-            unsigned char *dst = real ? smem + (c_chunk & 1) * HBYTES + (j * NW + wave) * 1024 : zero;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_chunk) * 128u : Y2_OOB, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < HSLOTS; ++j) {           // slots 0 .. c_tap-1 of the NEXT chunk's halo would have been issued by now
-            const bool real = j < c_tap && j * NW + wave < HPIECES && (c_chunk + 1) * TAPS < kt_end;
-            unsigned char *dst = real ? smem + ((c_chunk + 1) & 1) * HBYTES + (j * NW + wave) * 1024 : zero;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (__attribute__((address_space(3))) void *)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_chunk + 1) * 128u : Y2_OOB, 0, 0, 0);
-        }
-#pragma unroll
-        for (int d = 0; d < NSB - 1; ++d) issue_slot(-1, 0, kt_beg + d, d);
-    }
-    bf16x8 fa0[4][TM], fb0[4][TN], fa1[4][TM], fb1[4][TN];
-    FragAddr ad_next;                                    // addresses of the step after the one whose MFMAs run
-    int n_chunk = c_chunk, n_tap = c_tap;                // the K step ad_next belongs to
-    calc_addr(ad_next, n_chunk, n_tap, 0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 2) * Y2T_LOADS) : "memory");      // halo + filter tile kt_beg have landed (the newer slots stay in flight)
-    __builtin_amdgcn_s_barrier();
-    read_frags(fa0, fb0, ad_next);
-    next_step(n_chunk, n_tap);
-    calc_addr(ad_next, n_chunk, n_tap, 1);
-    int bstage_i = NSB - 1, bstage_n = 2;                // ring stage the next DMA slot fills / of the step after ad_next's
-    // One K step.  Its MFMAs run on (fa, fb), read during the previous step.  The first four are issued BEFORE the wait + barrier
-    // (they need registers only: the matrix pipe works while the workgroup's slowest wave arrives); behind the barrier come the
-    // DMA slot, then the other twelve MFMAs each followed by one or two of step kt+1's sixteen fragment reads, with the address
-    // arithmetic of step kt+2 in two of the gaps.  sched_barrier(0) after every group: the order below IS the issue order (left
-    // alone, the scheduler clusters the reads and puts MFMAs on the same accumulator back to back).
-    auto step = [&](int kt, bf16x8 (&fa)[4][TM], bf16x8 (&fb)[4][TN], bf16x8 (&na)[4][TM], bf16x8 (&nb)[4][TN]) {
-        auto mfma_one = [&](int kk, int w) {             // w: 0..3 = (i, j) of the accumulator tile
-            const int i = w >> 1, j = w & 1;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-        };
-        auto read_one = [&](int idx) {                   // idx 0..15: 16-k group idx / 4; order A0, B0, A1, B1
-            const int kk = idx >> 2, w = idx & 3;
-            if (w == 0 || w == 2) na[kk][w >> 1] = *(lds_frag_ptr)(uintptr_t)(ad_next.abase[w >> 1] + (ad_next.ax[w >> 1] ^ (unsigned)(kk * 32)));
-            else nb[kk][w >> 1] = *(lds_frag_ptr)(uintptr_t)(ad_next.bbase + (bx ^ (unsigned)(kk * 32)) + (unsigned)((w >> 1) * 32 * ROWB));
-        };
-#pragma unroll
-        for (int w = 0; w < 4; ++w) mfma_one(0, w);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSB - 3) * Y2T_LOADS) : "memory");      // all but the newest NSB-3 slots: steps kt and kt+1 are in LDS
-        __builtin_amdgcn_s_barrier();                    // ... for every wave; nobody reads step kt-1's operands any more
-        __builtin_amdgcn_sched_barrier(0);
-        FragAddr ad_new;
-        next_step(n_chunk, n_tap);
-        // fragment reads first (two behind each of eight MFMAs), the DMA slot after the last of them: a DMA piece issued while
-        // ds_reads are queued costs the wave 100-185 cycles of issue, 25-60 in a read-free gap (MI355X_MICROARCH.md)
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            mfma_one(1 + g / 4, g & 3);
-            if (g < 8) { read_one(2 * g); read_one(2 * g + 1); }
-            if (g == 8) calc_addr(ad_new, n_chunk, n_tap, bstage_n);          // step kt+2
-            if (g == 9 + (Y2T_DMA_EARLY ? -100 : 0)) issue_slot(c_tap, c_chunk + 1, kt + NSB - 1, bstage_i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        bstage_i = bstage_i == NSB - 1 ? 0 : bstage_i + 1;
-        ad_next = ad_new;
-        bstage_n = bstage_n == NSB - 1 ? 0 : bstage_n + 1;
-        next_step(c_chunk, c_tap);
-    };
-    {
-        int kt = kt_beg;
-        for (; kt + 1 < kt_end; kt += 2) {
-            step(kt, fa0, fb0, fa1, fb1);
-            step(kt + 1, fa1, fb1, fa0, fb0);
-        }
-        if (kt < kt_end) step(kt, fa0, fb0, fa1, fb1);
-    }
-
-    // ---- stream-K hand-off (as in conv_igemm_kernel: the workgroup holding K step 0 of a tile owns it; a tail segment is parked)
-    {
-        constexpr int SLOT = BM * BN;
-        const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
-        const unsigned slot_lane = (unsigned)(((size_t)wave * (TM * TN * 16 * 64) + (size_t)lane * 4) * sizeof(float));
-        if (kt_beg > 0) {
-            const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcS, mine + ((i * TN + j) * 4 + q4) * 1024, 0, 16);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            continue;
-        }
-        if (kt_end < nk) {
-            const long tile_end = su - kt_end + nk;
-            long covered = su;
-            for (int p = wx + 1; covered < tile_end; ++p) {
-                if (tid == 0) {
-                    while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) {
-                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS, theirs + ((i * TN + j) * 4 + q4) * 1024, 0, 16));
-                            acc[i][j][4 * q4] += v[0];
-                            acc[i][j][4 * q4 + 1] += v[1];
-                            acc[i][j][4 * q4 + 2] += v[2];
-                            acc[i][j][4 * q4 + 3] += v[3];
-                        }
-                covered = (long)(p + 1) * su_total / G;
-            }
-        }
-    }
-
-    // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave LDS image, 16-byte stores), with the
-    // forward statistics or the producer layer's BN-backward sums taken from the rounded values
-    {
-        const bool stats = !BNBWD && bn_part != nullptr;
-        const bool bstats = BNBWD && bn_part != nullptr;
-        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave row) pair
-        constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
-        static_assert(NW * WROWS * WSTRIDE <= 2 * HBYTES, "tile image fits the halo buffers");
-        float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
-        Vec16<T> yv[YG];
-        const int bz_nb = min(n0 + wn * TN * 32 + (lane % WCPR) * VEC, Nf - VEC);
-        auto bz_load_y = [&](int it0) {
-#pragma unroll
-            for (int u = 0; u < YG; ++u) {
-                const int m = min(m0 + wm * WROWS + ((it0 + u) * 64 + lane) / WCPR, M - 1);
-                yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
-            }
-        };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write the zero KiB only)
-        __syncthreads();                                      // every wave has finished reading the last step's operands
-        unsigned char *wreg = smem + wave * (WROWS * WSTRIDE);
-        const bool tail = m0 + BM > M;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
-            const bool n_ok = n < Nf;
-            const float bv = (bias && n_ok) ? bias[n] : 0.f;
-            const float sh = (stats && n_ok) ? bn_shift[n] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bv;
-                    if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
-                    const T o = (T)v;
-                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane & 31)) * 2) = o;
-                    if (stats && (!tail || m0 + wm * WROWS + row < M)) {
-                        const float d = (float)o - sh;
-                        s1 += d;
-                        s2 += d * d;
-                    }
-                }
-            }
-            if (stats) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lane < 32 && n_ok) {
-                    const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                    float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
-                    if (stats_unique) { *p1 = s1; *p2 = s2; }
-                    else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
-                }
-            }
-        }
-        if (bstats) {
-            bz_load_y(0);
-#pragma unroll
-            for (int k = 0; k < VEC; k += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + bz_nb + k), b = *reinterpret_cast<const f32x4 *>(bz.var + bz_nb + k);
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + bz_nb + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + bz_nb + k);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    cmu[k + q] = a[q];
-                    cinv[k + q] = 1.0f / sqrtf(b[q] + bz.eps);
-                    cga[k + q] = c[q];
-                    cbt[k + q] = d[q];
-                    ps[0][k + q] = ps[1][k + q] = 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int id = it * 64 + lane;
-            const int row = id / WCPR, ch = id % WCPR;
-            const int m = m0 + wm * WROWS + row;
-            const int n = n0 + wn * TN * 32 + ch * VEC;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
-            if (bstats && it && it % YG == 0) bz_load_y(it);
-            if (m < M && n < Nf) {
-                *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
-                if (bstats) {
-                    const Vec16<T> y = yv[it % YG];
-                    Vec16<T> d;
-                    d.v = __builtin_bit_cast(decltype(d.v), v);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        const float xh = (y.get(k) - cmu[k]) * cinv[k];
-                        const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
-                        const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
-                        ps[0][k] += g * xh;
-                        ps[1][k] += g;
-                    }
-                }
-            }
-        }
-        if (bstats) {
-#pragma unroll
-            for (int off = WCPR; off < 64; off <<= 1)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    ps[0][k] += __shfl_xor(ps[0][k], off, 64);
-                    ps[1][k] += __shfl_xor(ps[1][k], off, 64);
-                }
-            const int nb = n0 + wn * TN * 32 + lane * VEC;
-            if (lane < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (stats_unique) { p1[k] = ps[0][k]; p2[k] = ps[1][k]; }
-                    else { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
-                }
-            }
-        }
-    }
-  }
-}
-
 // f32 partial sums [M][Nf] -> O (dtype, pixel stride ldo) + bias
 template <typename T>
 __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float *__restrict__ bias, T *__restrict__ O, long M, int Nf, int ldo, float act_alpha) {
@@ -1007,21 +573,16 @@ __global__ void splitk_finish_kernel(const float *__restrict__ acc, const float 
 }
 
 struct Tune { int target_blocks; int wide; int remap; int stream; int cus; int stream_max_tiles; int bm256; };
-static const Tune &tune() {   // tuning knobs (defaults = measured best); env overrides are for A/B runs only
+static const Tune &tune() {   // shape-selection constants (each the measured best: profiles/r01_igemm_*.txt, r03_igemm_variant_sweep.txt); two run-time switches remain
     static Tune t = [] {
         Tune v{352, 1, -1, 1, 256, 255, 1};   // K slicing only for grids below half the chip (see choose_ksplit)
-        if (const char *e = getenv("YOLO2_IGEMM_BM256")) v.bm256 = atoi(e);
-        if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);       // 0: no stream-K anywhere (A/B, debugging a hand-off)
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             v.cus = prop.multiProcessorCount;
-        if (const char *e = getenv("YOLO2_IGEMM_STREAM_WGS")) v.cus = atoi(e);
+        if (const char *e = getenv("YOLO2_IGEMM_STREAM_WGS")) v.cus = atoi(e);      // workgroups of a stream-K launch (default: one per CU; yolo2_set_stream_workgroups at run time)
         v.stream_max_tiles = 3 * v.cus;
-        if (const char *e = getenv("YOLO2_IGEMM_STREAM_MAXTILES")) v.stream_max_tiles = atoi(e);
-        if (const char *e = getenv("YOLO2_KSPLIT_BLOCKS")) v.target_blocks = atoi(e);
-        if (const char *e = getenv("YOLO2_IGEMM_WIDE")) v.wide = atoi(e);
-        if (const char *e = getenv("YOLO2_IGEMM_REMAP")) v.remap = atoi(e);
         return v;
     }();
     return t;
@@ -1083,8 +644,6 @@ static thread_local int g_last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static thread_local int g_last_stat_rows = Y2_BN_PART_ROWS;
 // most rows the consumer's prologue accepts for Nf channels (elementwise.hip fin_shape_ok: rows x slice x 8 bytes <= 128 KB), <= 256
 static int y2_stat_rows_limit(int Nf, int vec) {
-    static const int cap = getenv("YOLO2_STAT_ROWS_CAP") ? atoi(getenv("YOLO2_STAT_ROWS_CAP")) : 1;      // A/B: 0 = up to 256 unique rows whatever the consumer reads
-    if (!cap) return Y2_BN_PART_ROWS;
     int lpr = Nf / vec;
     if (lpr > 16) lpr = 16;
     if (lpr < 1) lpr = 1;
@@ -1155,18 +714,19 @@ static constexpr bool igemm_wide_fits() {
 
 // tap-fused 3x3 variant on/off (default: env YOLO2_IGEMM_TAP, else on); yolo2_debug_set_igemm_tap flips it at run time so that
 // tests can compare both variants on the same inputs
-// 0 = per-tap kernels only, 1 = round-2 tap-fused kernel (conv3x3_tap_kernel), 2 = ping-pong tap-fused kernel (conv_pp.hip; default)
+// 0 = per-tap kernels only, non-zero = the ping-pong tap-fused kernel (conv_pp.hip) where its launch rule admits it (default).  (The round-2
+// tap-fused kernel it replaced -- slower on every layer it took, profiles/r04_pp2_sched_b16.txt column tap-r2 -- is gone.)
 static std::atomic<int> g_igemm_tap{getenv("YOLO2_IGEMM_TAP") ? atoi(getenv("YOLO2_IGEMM_TAP")) : 2};
 extern "C" int yolo2_debug_set_igemm_tap(int mode) {
-    g_igemm_tap.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+    g_igemm_tap.store(mode != 0 ? 2 : 0, std::memory_order_relaxed);
     return YOLO2_OK;
 }
 // ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
 // dmapos 0/1 = DMA pieces at the head of the LOAD phase / inside the MFMA phase; min_steps, min_share = the launch gates below (< 0: keep)
-static std::atomic<int> g_pp_grid{getenv("YOLO2_PP_GRID") ? atoi(getenv("YOLO2_PP_GRID")) : 0};
-static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_SCHED") ? atoi(getenv("YOLO2_PP_SCHED")) : 2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
-static std::atomic<long> g_pp_min_steps{getenv("YOLO2_PP_MIN_STEPS") ? atol(getenv("YOLO2_PP_MIN_STEPS")) : 18};
-static std::atomic<long> g_pp_min_share{getenv("YOLO2_PP_MIN_SHARE") ? atol(getenv("YOLO2_PP_MIN_SHARE")) : 26};
+static std::atomic<int> g_pp_grid{0};
+static std::atomic<int> g_pp_dmapos{2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
+static std::atomic<long> g_pp_min_steps{18};
+static std::atomic<long> g_pp_min_share{26};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
     if (grid != -1) g_pp_grid.store(grid, std::memory_order_relaxed);
     if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
@@ -1193,7 +753,7 @@ extern "C" int yolo2_get_stream_workgroups(void) {
 static Tune tune_now() {
     Tune t = tune();
     const int n = g_stream_wgs.load(std::memory_order_relaxed);
-    if (n > 0) { t.cus = n; if (!getenv("YOLO2_IGEMM_STREAM_MAXTILES")) t.stream_max_tiles = 3 * n; }
+    if (n > 0) { t.cus = n; t.stream_max_tiles = 3 * n; }
     return t;
 }
 
@@ -1212,8 +772,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     unsigned *sk_flags = nullptr;
     // 16-byte epilogue stores need 16-byte aligned pixel rows, and a partial last chunk may only spill into this tensor's own
     // padding lanes (written as zeros), never into a neighbouring concat slice
-    static const int env_wide = getenv("YOLO2_IGEMM_WIDE_STORE") ? atoi(getenv("YOLO2_IGEMM_WIDE_STORE")) : 1;
-    const int wide_store = env_wide && ((uintptr_t)O & 15) == 0 && ldo % VEC == 0 && (Nf % VEC == 0 || ldo < Nf + VEC);
+    const int wide_store = ((uintptr_t)O & 15) == 0 && ldo % VEC == 0 && (Nf % VEC == 0 || ldo < Nf + VEC);
     // XCD mapping: filter operand small -> contiguous M runs per XCD; else filter tiles pinned per XCD
     const int remap = tu.remap >= 0 ? tu.remap : (f_bytes <= (3u << 19) ? 1 : 0);
     const int MT2 = cdiv(M, 256), NT2 = cdiv(Nf, 128);
@@ -1222,11 +781,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     // (half the LDS fragment traffic and 25 % less DMA per flop than 32 x 64 per wave), always stream-K.  Measured
     // (profiles/r01_igemm_bm256.txt): +23 % on the 3072-channel layer; shorter reductions, fuller grids and grids under
     // 64 tiles (each tile cut into > 4 parts: the owner's serial fix-up) lose.
-    // 3x3 layers on images up to 55 pixels wide (the 52x52, 26x26 and 13x13 stages): tap-fused kernel, one halo image per 64-channel
-    // chunk instead of nine shifted pixel tiles (conv3x3_tap_kernel above), always stream-K over one workgroup per CU
     if constexpr (std::is_same<T, bf16>::value) {
         const int tap_mode = g_igemm_tap.load(std::memory_order_relaxed);
-        const int tap_on = tap_mode == 1;
         // Ping-pong tap-fused kernel (conv_pp.hip): 3x3 layers on images up to 55 wide whose input is a multiple of 64 channels.  Its
         // fixed cost per launch (~24 us: prologue, stream-K hand-off, epilogue) against ~0.65 us per K step decides where it wins
         // (profiles/r04_pp2_*.txt, r04_pp3_*.txt, batch 16 and 8):
@@ -1236,11 +792,11 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         //     56 vs 60 us, 129 vs 144 us; the 512-channel ones, 24.75 steps per workgroup, stay with the per-tap kernels);
         //   * a data gradient that also reduces the producer's BN-backward sums takes it from 10 steps per workgroup when it has >= 8192
         //     pixels: the per-tap kernels' form of that epilogue costs 12-30 us there, this one 4-7.
-        if (tap_mode == 2 && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream &&
+        if (tap_mode != 0 && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream &&
             (long)9 * (Cp / 64) >= g_pp_min_steps.load(std::memory_order_relaxed) && tu.cus <= Y2_STREAM_FLAG_WORDS) {
             const long tiles_t = (long)MT2 * NT2, units_p = tiles_t * 9 * (Cp / 64);
             const int gm = g_pp_grid.load(std::memory_order_relaxed);
-            const bool can_stream = (size_t)tu.cus * Y2T_BM * Y2T_BN * sizeof(float) <= ws_bytes;
+            const bool can_stream = (size_t)tu.cus * 256 * 128 * sizeof(float) <= ws_bytes;
             int grid = 0;
             if (gm == 1) grid = can_stream ? tu.cus : 0;
             else if (gm == 2) grid = tiles_t <= Y2_STREAM_FLAG_WORDS ? (int)tiles_t : 0;
@@ -1249,34 +805,13 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             else if (tiles_t * 10 >= (long)tu.cus * 6 && tiles_t <= tu.cus) grid = (int)tiles_t;
             else if (can_stream && (units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus || (bz.Y && M >= 8192 && units_p >= 10L * tu.cus))) grid = tu.cus;
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
-                const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
+                const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
                 const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
-                static const int k_rotate_pp = getenv("YOLO2_IGEMM_TAP_ROTATE") ? atoi(getenv("YOLO2_IGEMM_TAP_ROTATE")) : 1;
                 if (y2_conv3x3_pp_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_,
-                                         k_rotate_pp, grid, g_pp_dmapos.load(std::memory_order_relaxed), st) == 0)
+                                         /* K rotation of the stream-K tiles (profiles/r03_l2_stationary_ab.md) */ 1, grid, g_pp_dmapos.load(std::memory_order_relaxed), st) == 0)
                     return 0;
             }
-        }
-        // (measured, profiles/r02_igemm_tap.md: pays on the long reductions -- >= 1024 input channels; shorter ones keep the per-tap kernels)
-        static const long tap_min_steps = getenv("YOLO2_IGEMM_TAP_MIN_STEPS") ? atol(getenv("YOLO2_IGEMM_TAP_MIN_STEPS")) : 144;
-        // ... and when a workgroup's share is long enough to amortise the halo prologue of its (up to three) segments
-        static const long tap_min_share = getenv("YOLO2_IGEMM_TAP_MIN_SHARE") ? atol(getenv("YOLO2_IGEMM_TAP_MIN_SHARE")) : 40;
-        const long units_t = (long)MT2 * NT2 * 9 * (Cp / 64);
-        if (tap_on && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream && (long)9 * (Cp / 64) >= tap_min_steps &&
-            units_t >= tap_min_share * tu.cus && tu.cus <= Y2_STREAM_FLAG_WORDS && (size_t)tu.cus * Y2T_BM * Y2T_BN * sizeof(float) <= ws_bytes &&
-            (sk_flags = stream_flags()) != nullptr) {
-            const int plan_[8] = {Y2T_BM, Y2T_BN, 8, 8, 9, 2, tu.cus, 1};      // "stages" 9: nine taps per halo image
-            for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
-            const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
-            static const int k_rotate = getenv("YOLO2_IGEMM_TAP_ROTATE") ? atoi(getenv("YOLO2_IGEMM_TAP_ROTATE")) : 1;       // A/B: 0 = every tile starts at K step 0
-#define Y2T_LAUNCH(BWDv, HRv, NSBv)                                                                                                      \
-            conv3x3_tap_kernel<BWDv, HRv, NSBv><<<dim3(tu.cus), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
-                                                                              H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_, k_rotate)
-            if (W <= 27) { if (bz.Y) Y2T_LAUNCH(true, 312, 5); else Y2T_LAUNCH(false, 312, 5); }
-            else { if (bz.Y) Y2T_LAUNCH(true, 368, 4); else Y2T_LAUNCH(false, 368, 4); }
-#undef Y2T_LAUNCH
-            return 0;
         }
     }
     if (Nf > 64 && tu.bm256 && ws && tu.stream && nk_wide >= 128 && MT2 * NT2 >= 64 && MT2 * NT2 <= 3 * tu.cus && tu.cus <= Y2_STREAM_FLAG_WORDS &&
@@ -1320,9 +855,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         } else {
             ws = nullptr;
             dim3 grid(MT * NT);
-            static const int ns2 = getenv("YOLO2_IGEMM_WIDE_NS2") ? atoi(getenv("YOLO2_IGEMM_WIDE_NS2")) : 1;
             if (wide) Y2_IGEMM_KS_WIDE(0, grid);
-            else if (ns2 && Cp % (8 * VEC) == 0) {
+            else if (Cp % (8 * VEC) == 0) {
                 // full grids with >= 64 channels: 128-byte rows on a 2-stage ring (64 KiB: two workgroups per CU, 8 MFMAs per
                 // wave between barriers instead of 4) -- +8..19 % on the 52x52 / 26x26 stages (profiles/r01_igemm_wide_ns2.txt)
                 if (ksize == 3) Y2_IGEMM(128, 2, 2, 3, 0, false, 8, 8, grid);
@@ -1333,8 +867,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         const int NT = 1;
         ws = nullptr;
         dim3 grid(MT);
-        static const int small_wide = getenv("YOLO2_IGEMM_SMALL_WIDE") ? atoi(getenv("YOLO2_IGEMM_SMALL_WIDE")) : 1;
-        if (small_wide && ksize == 3 && Cp % (8 * VEC) == 0) {
+        if (ksize == 3 && Cp % (8 * VEC) == 0) {
             // 3x3 with <= 64 filters and >= 64 channels (the 208x208 / 104x104 data gradients): 128-byte rows, 2-stage ring;
             // +35 % / +20 % on those two launches; the 1x1 layers measured no gain (profiles/r01_igemm_wide_ns2.txt)
             if (Nf > 32) Y2_IGEMM(64, 1, 2, 3, 0, false, 8, 4, grid);

@@ -58,6 +58,8 @@ constexpr int y2p_leave(int order, int D, int tp, int hslots, bool skipidle) {
 //   4  reads + the two filter pieces in the LOAD phase, the halo piece behind the first four MFMAs
 //   5  as 2, but the pixel (A) fragments of step s+1 are read behind the MFMAs of step s, each 16-k group into the registers its four
 //      MFMAs have just released: the LOAD phase keeps the eight filter reads + the pieces and becomes shorter than the MFMA phase
+//   6  NO ping-pong: all eight waves in the same step, one barrier per step; the fragments of step s+1 (pixels and filters) are read
+//      behind the MFMAs of step s, each 16-k group into the registers its four MFMAs have just released
 //   +8  slots of taps >= HSLOTS carry no halo piece at all (2 instead of 3 instructions; the counted waits use the exact per-tap sums)
 //   +16 s_setprio 1 for the MFMA phase
 template <bool BNBWD, int HROWS, int NSB, int SCHED>
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
+    if (ORDER != 6 && wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
     __builtin_amdgcn_sched_barrier(0);
 
     bf16x8 fa[4][TM], fb[4][TN];
@@ -275,6 +277,57 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 auto dma_halo = [&]() { if (has_halo && !A_NODMA) issue_halo(tp, c + 1, mc1, tp < HSLOTS && next_ok); };
                 // DMA instructions this wave may leave in flight at the end of LOAD(tp): everything issued after its pieces of step kt+1
                 constexpr int LEAVE = y2p_leave(ORDER, D, tp, HSLOTS, SKIPIDLE);
+                if constexpr (ORDER == 6) {
+                    // ---- single-phase software pipeline (no ping-pong): all eight waves run the same step; a step's MFMAs use fragments read
+                    // during the previous step, and each 16-k group's registers are refilled with the NEXT step's fragments right behind the four
+                    // MFMAs that released them.  Both waves of a SIMD feed the matrix pipe, covering each other's read / DMA issue bubbles.
+                    const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
+                    if (kt == kt_beg && !A_NOREAD) {                   // first step of the segment: nobody has read its fragments yet
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
+                            const unsigned bb = baddr[kk] + so;
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // this wave's pieces of step kt+1 have landed: of the D-1 slots issued so far beyond step kt, the newest D-2 stay in flight
+                    if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(y2p_leave(1, D, tp, HSLOTS, SKIPIDLE)) : "memory");
+                    __builtin_amdgcn_s_barrier();          // ... for every wave; and nobody reads the ring stage of step kt-1 any more
+                    __builtin_amdgcn_sched_barrier(0);
+                    dma_halo();
+                    dma_filter();
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bool pre = !A_NOREAD && kt + 1 < kt_end;
+                    const unsigned so1 = (unsigned)((stage_r == NSB - 1 ? 0 : stage_r + 1) * Y2P_BBYTES);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+                                if (!A_NOMFMA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // Every read of the previous step has long returned here (its last group was issued a barrier, three DMA pieces and four
+                        // MFMAs ago).  Saying so through the builtin keeps hipcc's wait insertion exact: without it, it counts those sixteen
+                        // reads as outstanding and puts lgkmcnt(5) / lgkmcnt(1) before the later MFMA groups -- which wait for THIS step's
+                        // trailing reads.
+                        if (kk == 0) __builtin_amdgcn_s_waitcnt(0xc07f);
+                        if (pre) {
+#pragma unroll
+                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[(tp + 1) % TAPS][i] ^ (unsigned)(kk * 32));
+                            const unsigned bb = baddr[kk] + so1;
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++kt;
+                    stage_r = stage_r == NSB - 1 ? 0 : stage_r + 1;
+                    stage_i = stage_i == NSB - 1 ? 0 : stage_i + 1;
+                } else {
                 // ---- LOAD phase
                 if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
@@ -345,6 +398,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 ++kt;
                 stage_r = stage_r == NSB - 1 ? 0 : stage_r + 1;
                 stage_i = stage_i == NSB - 1 ? 0 : stage_i + 1;
+                }
             }
             // the next chunk reads the other halo buffer (every tap's addresses move, whether or not this segment ran the tap)
 #pragma unroll
@@ -361,7 +415,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         step(std::integral_constant<int, 8>{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
+    if (ORDER != 6 && wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
     __builtin_amdgcn_sched_barrier(0);
 
     // Everything below indexes by (lane_e, wave_e): copies the compiler cannot see through, so that none of the hand-off / epilogue
@@ -476,10 +530,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         }
         if (bstats) {
             bz_load_y(0);
+            // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
+            // loop, where the 64 accumulator registers are still live -- the BN-backward instantiations then need 245 .. 256+ registers)
+            int nb_c = bz_nb;
+            asm volatile("" : "+v"(nb_c));
 #pragma unroll
             for (int k = 0; k < VEC; k += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + bz_nb + k), b = *reinterpret_cast<const f32x4 *>(bz.var + bz_nb + k);
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + bz_nb + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + bz_nb + k);
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + nb_c + k), b = *reinterpret_cast<const f32x4 *>(bz.var + nb_c + k);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + nb_c + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + nb_c + k);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     cmu[k + q] = a[q];
@@ -566,14 +624,14 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         return 0;
     if (sched >= 64) {
         switch (sched) {
-            Y2P_ABL_CASE(5 + 64) Y2P_ABL_CASE(5 + 128) Y2P_ABL_CASE(5 + 256) Y2P_ABL_CASE(5 + 64 + 128) Y2P_ABL_CASE(5 + 128 + 256) Y2P_ABL_CASE(5 + 64 + 128 + 256)
-            Y2P_ABL_CASE(5 + 64 + 256)
+            Y2P_ABL_CASE(6 + 64) Y2P_ABL_CASE(6 + 128) Y2P_ABL_CASE(6 + 256) Y2P_ABL_CASE(6 + 64 + 128) Y2P_ABL_CASE(6 + 128 + 256) Y2P_ABL_CASE(6 + 64 + 128 + 256)
+            Y2P_ABL_CASE(6 + 64 + 256)
             default: return 1;
         }
     }
 #undef Y2P_ABL_CASE
     switch (sched & 31) {
-        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(5) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(13) Y2P_CASE(18) Y2P_CASE(26)
+        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(5) Y2P_CASE(6) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(13) Y2P_CASE(14) Y2P_CASE(18) Y2P_CASE(26)
         default: break;
     }
 #endif

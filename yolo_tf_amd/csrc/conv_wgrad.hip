@@ -391,12 +391,12 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     const int tgroups = (BC == 64 && wgrad_pairs_taps(Cin, ksize)) ? (ksize * ksize + 1) / 2 : ksize * ksize;
     p.tiles = tgroups * CT * NT;
     static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
-    static const int env_remap = getenv("YOLO2_WGRAD_REMAP") ? atoi(getenv("YOLO2_WGRAD_REMAP")) : -1;
+    const int env_remap = -1;      // (XCD-local placement by rule below)
     // 128-wide tile (8 waves, two workgroups per CU): every block of the grid should be resident at once -- AT MOST 7/4 blocks per CU --
     // and keep >= 40 reduction tiles, else the 64 KB atomic epilogue and the ring prologue dominate.  26x26 256->512 (72 tiles),
     // profiles/r03_wgrad_split_sweep.txt: 8 ranges = 576 blocks 55.7 us, 6 = 432 blocks 49.6 us at batch 16; 42.2 -> 34.3 us at batch 8
     // with 4; 84.8 -> 79.6 us at batch 32 with 6.  64-wide tile: >= 8 reduction tiles per block.
-    static const int resident = getenv("YOLO2_WGRAD_RESIDENT") ? atoi(getenv("YOLO2_WGRAD_RESIDENT")) : 1;      // A/B: 0 = ~512 blocks, >= 8 reduction tiles
+    const int resident = 1;
     const bool res = BC >= 128 && resident && env_target <= 0;
     const int max_ks = res ? (M / (40 * BKP) > 1 ? M / (40 * BKP) : 1) : cdiv(M, 8 * BKP);
     // 64-wide tile: ~1024 blocks for the 3x3 layers, ~384 for the 1x1 layers (9x fewer tiles: more, shorter pixel ranges only add
@@ -417,9 +417,7 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     }
     // a tile grid that already covers the chip takes ONE pixel range: no atomics, plain stores (measured: the atomic epilogue
     // of a 2-way split costs more than the second workgroup per tile gains)
-    static const int direct_min = getenv("YOLO2_WGRAD_DIRECT_MIN_TILES") ? atoi(getenv("YOLO2_WGRAD_DIRECT_MIN_TILES")) : 256;
-    static const int single_order = getenv("YOLO2_WGRAD_SINGLE_ORDER") ? atoi(getenv("YOLO2_WGRAD_SINGLE_ORDER")) : 1;       // A/B: 0 = plain tile order
-    if (direct_min > 0 && p.tiles >= direct_min) { ks = 1; remap = single_order ? 2 : 0; }
+    if (p.tiles >= 256) { ks = 1; remap = 2; }      // (L2-stationary tile order: profiles/r03_l2_stationary_ab.md)
     if (ks < 1) ks = 1;
     p.mchunk = cdiv(cdiv(M, ks), BKP) * BKP;
     ks = cdiv(M, p.mchunk);
@@ -441,7 +439,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
     const int direct = pl.ks == 1;                            // one pixel range: plain stores, dW need not be zeroed
     dim3 grid(pl.blocks);
     const unsigned x_bytes = (unsigned)((size_t)M * ldx * sizeof(T)), y_bytes = (unsigned)((size_t)M * ldy * sizeof(T));
-    static const int nw8 = getenv("YOLO2_WGRAD_NW8") ? atoi(getenv("YOLO2_WGRAD_NW8")) : 1;
+    const int nw8 = 1;      // (8-wave workgroups for the 128-wide tile: profiles/r01_wgrad_variants.txt)
     {
         const bool w8 = BC >= 128 && g_wgrad_variant == 0 && nw8, pair = BC == 64 && g_wgrad_variant == 0 && wgrad_pairs_taps(Cin, ksize);
         const int plan[8] = {BC, BNN, w8 ? 8 : 4, pair ? 1 : 0, pl.ks, remap, pl.blocks, direct};
@@ -468,7 +466,7 @@ static void launch_wgrad(const void *X, const void *dY, float *dW, int B, int H,
 static bool wgrad_small_tile(int Cin, int Cout, int ksize) {
     // few 128x128 tiles (1x1 layers, 128->256 3x3): the 64x64 tile quarters the pixel-range split and its atomic traffic
     // (26 -> 20 us on the 1x1 layers; profiles/r01_wgrad_small_tiles.txt)
-    static const int small_below = getenv("YOLO2_WGRAD_SMALL_BELOW") ? atoi(getenv("YOLO2_WGRAD_SMALL_BELOW")) : 33;
+    const int small_below = 33;
     return Cin <= 64 || Cout <= 64 || ksize * ksize * cdiv(Cin, 128) * cdiv(Cout, 128) < small_below;
 }
 
@@ -508,10 +506,9 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     } else {
         // 64-pixel reduction tiles on a 2-stage ring (8 MFMAs per wave between barriers, same 64 KiB of LDS): pays when the launch gives
         // a CU about one workgroup -- single-range grids of up to 1.5 blocks per CU (the 512 -> 1024 13x13 layers: 41.9 -> 36.6 us);
-        // with two or three workgroups per CU the 32-pixel / 3-stage form wins (conv18: 66.5 vs 73.1 us).  YOLO2_WGRAD_BKP64=0 / 1: never / always.
-        static const int bkp64 = getenv("YOLO2_WGRAD_BKP64") ? atoi(getenv("YOLO2_WGRAD_BKP64")) : -1;
-        bool use64 = bkp64 == 1;
-        if (bkp64 < 0 && dtype == YOLO2_BF16 && g_wgrad_variant == 0) {
+        // with two or three workgroups per CU the 32-pixel / 3-stage form wins (conv18: 66.5 vs 73.1 us).
+        bool use64 = false;
+        if (dtype == YOLO2_BF16 && g_wgrad_variant == 0) {
             int dev = 0, cus = 256;
             hipDeviceProp_t prop;
             static int cached_cus = 0;

@@ -365,7 +365,7 @@ static int colsum_grid(long M, int C, int vec) {
     int tpr = C / vec, rpp = 256 / tpr;
     if (rpp < 1) rpp = 1;
     long g = (M + (long)rpp * 4 - 1) / ((long)rpp * 4);
-    static const int cap = [] { const char *e = getenv("YOLO2_COLSUM_BLOCKS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }();
+    const int cap = 256;
     if (g > cap) g = cap;       // default 1 workgroup per CU (measured best: 64..1024 swept); keeps the finalisation short (workspace contract: <= 1024)
     if (g < 1) g = 1;
     return (int)g;
@@ -541,7 +541,7 @@ extern "C" int yolo2_bias_grad(const void *dY, int ld, float *dbias, double *ws,
         return YOLO2_OK;
     }
     Y2_CHECK_ARG(ld % vec == 0);
-    static const long direct_rows = getenv("YOLO2_BIAS_GRAD_DIRECT_ROWS") ? atol(getenv("YOLO2_BIAS_GRAD_DIRECT_ROWS")) : 8192;
+    const long direct_rows = 8192;
     if (M <= direct_rows && ((uintptr_t)dY & 15) == 0) {
         Y2_DISPATCH_DTYPE(dtype, colsum_direct_kernel<T><<<cdiv(C, vec), 256, 0, st>>>((const T *)dY, ld, M, C, dbias));
         Y2_CHECK_LAUNCH();
@@ -1841,7 +1841,7 @@ static int pool_bwd_reduce_impl(const void *dP, int lddp, const unsigned char *i
     int nb = colsum_grid(MP, C, vec);
     // the 416x416 / 208x208 stages (> 64 MB of conv output): one workgroup per CU is latency-bound at 3 TB/s (measured 80 -> 62 us
     // with four); smaller tensors keep the short finalisation
-    static const int big = getenv("YOLO2_POOL_REDUCE_BLOCKS") ? atoi(getenv("YOLO2_POOL_REDUCE_BLOCKS")) : 1024;
+    const int big = 1024;
     if (big > nb && (long)B * H * W * C * (16 / vec) >= (64L << 20)) {
         const int tpr = C / vec, rpp = 256 / tpr < 1 ? 1 : 256 / tpr;
         long g = (MP + (long)rpp * 4 - 1) / ((long)rpp * 4);
@@ -1966,7 +1966,7 @@ extern "C" int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const vo
     Y2_CHECK_ARG(C % vec == 0 && C / vec <= 256 && ldda % vec == 0);
     int nb = colsum_grid(M, C, vec);
     // > 32 MB to read (the pooled 208x208 / 104x104 stages): one workgroup per CU is latency-bound, as for the pooled reduction above
-    static const int big = getenv("YOLO2_REDUCE_PART_BLOCKS") ? atoi(getenv("YOLO2_REDUCE_PART_BLOCKS")) : 1024;
+    const int big = 1024;
     if (big > nb && M * C * (16 / vec) * 2 >= (32L << 20)) {
         const int tpr = C / vec, rpp = 256 / tpr < 1 ? 1 : 256 / tpr;
         const long g = (M + (long)rpp * 16 - 1) / ((long)rpp * 16);

@@ -55,7 +55,7 @@ def layer_end_offsets(graph, offsets):
     return ends
 
 
-_SKEW_KB = int(os.environ.get('YOLO2_ALLOC_SKEW_KB', '20'))
+_SKEW_KB = 20        # (profiles/r03_arena_stagger.txt)
 _skew_counter = [0]
 
 
@@ -232,7 +232,7 @@ class Engine(object):
         self._bindings = {}
         self._tmp_roots = {}
         self.fold_finalize = os.environ.get('YOLO2_FOLD_FINALIZE', '1') != '0' and not self.sync_bn
-        self.pool_ymax = self.fold_finalize and os.environ.get('YOLO2_POOL_YMAX', '1') != '0'
+        self.pool_ymax = self.fold_finalize
         self._bind(self.graph)
         self.fold_bn = os.environ.get('YOLO2_FOLD_BN', '1') != '0'
         self.fuse_bn_stats = os.environ.get('YOLO2_FUSE_BN_STATS', '1') != '0'
@@ -263,7 +263,7 @@ class Engine(object):
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
             self.side_stream = torch.cuda.Stream(device=dev)
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
-            self.overlap_max_m = int(os.environ.get('YOLO2_OVERLAP_MAX_M', str(1 << 40)))   # A/B: overlap only layers with at most this many output pixels
+            self.overlap_max_m = 1 << 40   # A/B: overlap only layers with at most this many output pixels
         self.img = None
 
     def _bind(self, graph):
@@ -306,7 +306,7 @@ class Engine(object):
                 if (self.training and op['kind'] == 'pool' and op['stride'] == 2 and x in producers and producers[x]['bn'] and x not in fused_pool
                         and uses.get(x, 0) > 1 and x.h % 2 == 0 and x.w % 2 == 0 and act[x][1] == x.c and act[op['out']][1] == op['out'].c
                         and act[producers[x]['y']][1] == x.c and x.c // (8 if T == torch.bfloat16 else 4) <= 256
-                        and os.environ.get('YOLO2_FUSE_POOL_FANOUT', '1') != '0'):
+                        ):
                     fwd_pool[x] = op
         # BN-backward sums in the consumer's data-gradient epilogue: a batch-normalised conv whose full-resolution activation has
         # exactly one reader, a convolution writing that activation's gradient directly (no concat slice, no fan-out)
@@ -321,10 +321,10 @@ class Engine(object):
                 x = op.get('x')
                 # (measured per layer, profiles/r03_bn_bwd_fusion_per_layer.txt: in a single-stream trace the epilogue sums win 3-10 us per
                 # launch up to 26x26 at batch 16 and lose 1-13 us on the 52x52 / 104x104 layers; with the filter gradients overlapped on the
-                # side stream the whole step is equal either way, so every qualifying layer stays fused -- YOLO2_FUSE_BN_BWD_MAX_M limits it)
+                # side stream the whole step is equal either way, so every qualifying layer stays fused)
                 if (op['kind'] == 'conv' and x in producers and producers[x]['bn'] and 'fold_bias' not in self.conv[producers[x]['name']]
                         and uses.get(x, 0) == 1 and x not in fused_pool and x in gact and gact[x][1] == x.c and act[producers[x]['y']][1] == x.c
-                        and B * x.h * x.w <= int(os.environ.get('YOLO2_FUSE_BN_BWD_MAX_M', str(1 << 40)))):
+                        ):
                     bn_bwd_fused[op['name']] = producers[x]
         inp = next(iter(graph.inputs.values()))
         self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {},
@@ -461,7 +461,7 @@ class Engine(object):
         pixel ranges per tile).  Layers whose filter gradient is a single range store directly -- at batch 16 those are
         the three 13x13 layers that hold 70 % of the parameters -- and BN / bias gradients are stored by their
         finalisation kernels, so most of the 268 MB arena is never cleared."""
-        if os.environ.get('YOLO2_ZERO_ALL_GRADS', '0') != '0':
+        if False:        # (debugging aid: clear the whole gradient arena every step)
             return [(0, self.n_params)]
         ranges = []
         for op in self.graph.ops:

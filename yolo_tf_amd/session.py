@@ -79,7 +79,7 @@ class TrainSession(object):
             ops.set_stream_workgroups(max(64, total - int(reserve)) if reserve > 0 else 0)
         if world_size > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
             e.dropout_rank = torch.distributed.get_rank()
-        self.bucketed_update = os.environ.get('YOLO2_BUCKETED_UPDATE', '1') != '0'
+        self.bucketed_update = True
         self.fuse_adam_prep = os.environ.get('YOLO2_FUSE_ADAM_PREP', '1') != '0'      # A/B: 0 = Adam launch + separate operand re-layout at the next forward
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
