@@ -240,6 +240,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--grad-dtype', default=None, choices=['f32', 'bf16'], help='wire format of the gradient all-reduce (N > 1); default: [mi355x] grad_dtype')
+    ap.add_argument('--shard-optimizer', action='store_true', help='N > 1: reduce-scatter + 1/N optimizer pass + all-gather instead of all-reduce + replicated update ([mi355x] shard_optimizer)')
     ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
     args = ap.parse_args()
 
@@ -275,7 +276,8 @@ def main():
     builder, cfg = make_builder('darknet', args.names, args.size, True, basedir)
     grad_dtype = args.grad_dtype or (cfg.get('mi355x', 'grad_dtype') if cfg.has_option('mi355x', 'grad_dtype') else 'f32')
     sess = TrainSession(builder, args.batch, dtype=args.dtype, optimizer='adam', learning_rate=1e-6, seed=0, world_size=world,
-                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'), grad_dtype=grad_dtype)
+                        bucket_mb=cfg.getfloat('mi355x', 'bucket_mb'), grad_dtype=grad_dtype,
+                        shard_optimizer=args.shard_optimizer or (cfg.has_option('mi355x', 'shard_optimizer') and cfg.getboolean('mi355x', 'shard_optimizer')))
     cells = args.size // 32
     gen = torch.Generator(device='cuda').manual_seed(1234 + rank)
     images = torch.rand(args.batch, args.size, args.size, 3, device='cuda', generator=gen) * 255.0
@@ -343,7 +345,8 @@ def main():
                                    % ('VOC' if args.names == 20 else 'COCO', args.names, args.size, args.size, args.batch,
                                       'BASELINE configs[2]' if (strong and args.names == 80) else 'BASELINE configs[1]' if (args.names == 20 and args.batch == 16) else 'variant'),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world, 'optimizer': 'adam', 'weights': 'random-init (Xavier, seed 0)',
-                       'collective': ('RCCL all-reduce (%s, %s gradients), %d ranks, %d buckets' % (dist.get_backend(), grad_dtype, dist.get_world_size(), len(sess.reducer.buckets)))
+                       'collective': ('RCCL %s (%s, %s gradients), %d ranks, %d buckets' % ('reduce-scatter + sharded update + all-gather' if sess.shard_optimizer else 'all-reduce',
+                                                                                    dist.get_backend(), grad_dtype, dist.get_world_size(), len(sess.reducer.buckets)))
                        if world > 1 else 'none (1 rank)',
                        'env_overrides': _lib_env_overrides()},       # YOLO2_* A/B switches in effect ([] = the tested defaults)
             'whole_step_tflops': value * gflop / 1e3,

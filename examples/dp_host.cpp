@@ -119,6 +119,39 @@ static int run_rank(int rank, int world, const char *id_path) {
         hw = wn;
         for (int b = 0; b < 3; ++b) { (void)hipEventDestroy(ready[b]); (void)hipEventDestroy(landed[b]); }
     }
+    {   // ---- optimizer sharding ([mi355x] shard_optimizer): reduce-scatter every bucket, Adam on THIS rank's shard only, all-gather the updated
+        //      parameter shards -- all on the communication stream; the remainder of a bucket (< world * 64 elements) stays replicated
+        for (long i = 0; i < N; ++i) h[i] = (float)((i * 7 + rank * 13) % 251 - 125) / 64.0f;
+        HIP_OK(hipMemcpyAsync(g, h.data(), N * 4, hipMemcpyHostToDevice, compute));
+        HIP_OK(hipMemsetAsync(m, 0, N * 4, compute)); HIP_OK(hipMemsetAsync(v, 0, N * 4, compute));
+        const float lr = 1e-3f, b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, alpha = lr * std::sqrt(1.0f - b2) / (1.0f - b1);
+        hipEvent_t ready;
+        HIP_OK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        for (int b = 0; b < 3; ++b) {
+            const long s = bounds[b], n = bounds[b + 1] - bounds[b], L = n / ((long)world * 64) * 64, rem = n - (long)world * L;
+            HIP_OK(hipEventRecord(ready, compute));
+            HIP_OK(hipStreamWaitEvent(commst, ready, 0));
+            if (L) COMM_OK(yolo2_comm_reduce_scatter_bucket(comm, g + s, L, YOLO2_COMM_F32, commst));
+            if (rem) COMM_OK(yolo2_comm_allreduce_bucket(comm, g + s + world * L, rem, YOLO2_COMM_F32, commst));
+            const long o = s + (long)rank * L;
+            if (L) Y2_OK(yolo2_adam(w + o, g + o, m + o, v + o, L, alpha, b1, b2, eps, 1.0f / (float)world, commst));
+            if (rem) Y2_OK(yolo2_adam(w + s + world * L, g + s + world * L, m + s + world * L, v + s + world * L, rem, alpha, b1, b2, eps, 1.0f / (float)world, commst));
+            if (L) COMM_OK(yolo2_comm_allgather(comm, w + s, L * 4, commst));
+        }
+        HIP_OK(hipStreamSynchronize(commst));
+        std::vector<float> wn(N);
+        HIP_OK(hipMemcpy(wn.data(), w, N * 4, hipMemcpyDeviceToHost));
+        double worst_w = 0;
+        for (long i = 0; i < N; i += 509) {
+            double sum = 0;
+            for (int r = 0; r < world; ++r) sum += (double)((i * 7 + r * 13) % 251 - 125) / 64.0;
+            const double ga = sum / world, m1 = (1 - b1) * ga, v1 = (1 - b2) * ga * ga;
+            worst_w = fmax(worst_w, fabs(wn[i] - ((double)hw[i] - alpha * m1 / (std::sqrt(v1) + eps))));
+        }
+        if (worst_w > 2e-6) { fprintf(stderr, "rank %d: sharded update: weight error %.3g\n", rank, worst_w); return 10; }
+        hw = wn;
+        (void)hipEventDestroy(ready);
+    }
     // ---- a decision all ranks take together (train.py's agree()): only the last rank saw a problem
     int verdict = -1;
     COMM_OK(yolo2_comm_agree_max(comm, rank == world - 1 ? 1 : 0, &verdict, scratch, commst));

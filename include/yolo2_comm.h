@@ -38,6 +38,14 @@ int yolo2_comm_rank(const yolo2_comm *comm);
 int yolo2_comm_world(const yolo2_comm *comm);
 /* in-place sum over all ranks of `count` elements at buf (one gradient bucket), enqueued on `stream` */
 int yolo2_comm_allreduce_bucket(yolo2_comm *comm, void *buf, long count, int dtype, void *stream);
+/* Optimizer sharding ([mi355x] shard_optimizer; yolo_tf_amd/parallel.py GradReducer shard_params): instead of all-reducing a bucket and
+ * running the same optimizer pass on every rank, reduce-scatter it (rank r keeps the sum of elements [r * shard_count, (r+1) * shard_count)
+ * of buf, in place), update that shard alone (yolo2_adam & co. over the slice, gscale = 1 / world) and all-gather the updated PARAMETER
+ * shards (buf = the same range of the parameter arena, shard_bytes = shard_count * 4).  The host cuts every bucket into world equal
+ * shards of a multiple of 64 elements; the remainder (< world * 64 elements) goes through yolo2_comm_allreduce_bucket and stays
+ * replicated.  Same bytes on the wire as the all-reduce; the optimizer pass shrinks to 1 / world per rank. */
+int yolo2_comm_reduce_scatter_bucket(yolo2_comm *comm, void *buf, long shard_count, int dtype, void *stream);
+int yolo2_comm_allgather(yolo2_comm *comm, void *buf, long shard_bytes, void *stream);
 /* `bytes` bytes at buf become root's on every rank (initial replica: parameters, moving statistics, optimizer slots) */
 int yolo2_comm_broadcast(yolo2_comm *comm, void *buf, long bytes, int root, void *stream);
 /* a host-side decision every rank must take together (non-finite loss, a corrupt shard seen by one rank): the maximum of

@@ -897,3 +897,92 @@ def test_sync_bn_two_ranks_equal_one_process_with_the_joint_batch(tmp_path, base
     p_joint = e.params.cpu().numpy()
     agree = float(np.mean(np.abs(r0['params'] - p_joint) <= 1e-6))     # (a gradient whose sign differs -- |g| at rounding level -- moves by 2 alpha = 2e-3)
     assert agree >= 0.90, agree
+
+
+def _shard_opt_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    import torch.distributed as dist
+    from yolo_tf_amd.parallel import GradReducer, init_distributed
+    from yolo_tf_amd.session import TrainSession
+    torch.cuda.set_device(0)
+    init_distributed(backend='gloo')                    # both ranks share the one GPU of the test box: gloo carries the CUDA tensors
+    d = np.load(os.path.join(outdir, 'data.npz'))
+    images = torch.from_numpy(d['images'][2 * rank:2 * rank + 2]).cuda()
+    labels = [d['l%d' % i][2 * rank:2 * rank + 2] for i in range(6)]
+    out = {}
+    # (a) the exchange + update on IDENTICAL local gradients (a second backward would differ in the last bits: f32 atomics): the sharded
+    #     chain -- reduce-scatter, Adam on the own shard, all-gather -- against all-reduce + Adam over the whole arena
+    b, _ = make_builder('tiny', 20, 96, True, os.path.join(outdir, 'base%d' % rank))
+    sess = TrainSession(b, 2, dtype='f32', optimizer='adam', learning_rate=1e-3, seed=3, world_size=world, bucket_mb=4.0, shard_optimizer=True)
+    e, opt = sess.engine, sess.optimizer
+    assert sess.shard_optimizer and len(sess.reducer.buckets) >= 3
+    sess.upload_labels(labels)
+    keep = sess.reducer
+    sess.reducer = None
+    sess.forward_backward(images)                        # local gradients, no collective
+    sess.reducer = keep
+    torch.cuda.synchronize()
+    local_g, p0 = e.grads.clone(), e.params.clone()
+    g_sum = local_g.clone()
+    dist.all_reduce(g_sum)
+    e.grads.copy_(g_sum)
+    opt.apply(e.params, e.grads, 1e-3, 1, 1.0 / world)
+    torch.cuda.synchronize()
+    out['rep/params'], out['rep/m'], out['rep/v'] = e.params.cpu().numpy(), opt.slots[0].cpu().numpy(), opt.slots[1].cpu().numpy()
+    e.params.copy_(p0)
+    e.grads.copy_(local_g)
+    for sl in opt.slots:
+        sl.zero_()
+    red = GradReducer(e.grads, list(e.param_offsets.values()), 4.0, shard_params=e.params)
+    red.update_fn = lambda lo, hi: opt.apply(e.params, e.grads, 1e-3, 1, 1.0 / world, lo, hi)
+    red.begin()
+    red.finish(wait=True)
+    red.gather_slots(opt.slots)
+    torch.cuda.synchronize()
+    out['sh/params'], out['sh/m'], out['sh/v'] = e.params.cpu().numpy(), opt.slots[0].cpu().numpy(), opt.slots[1].cpu().numpy()
+    # (b) the session path: three sharded steps (chains enqueued during backward, update on the communication stream)
+    for sl in opt.slots:
+        sl.zero_()
+    e.params.copy_(p0)
+    e._filters_dirty = True
+    for step in range(3):
+        sess.upload_labels(labels)
+        sess.step(images)
+    sess.gather_optimizer_state()
+    torch.cuda.synchronize()
+    assert sess.global_step == 3
+    out['steps/params'], out['steps/m'] = e.params.cpu().numpy(), opt.slots[0].cpu().numpy()
+    out['p0'] = p0.cpu().numpy()
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_sharding_two_ranks_equal_replicated_update(tmp_path):
+    """[mi355x] shard_optimizer on the GPU, two ranks.  On identical local gradients the sharded exchange + update leaves parameters and
+    (gathered) Adam moments bit-identical to all-reduce + the replicated update; through TrainSession.step the replicas stay bit-identical
+    to each other and every parameter with a gradient moves."""
+    import socket
+    import torch.multiprocessing as mp
+    from yolo_tf_amd.utils import data
+    rng = np.random.RandomState(21)
+    images = rng.uniform(0, 255, (4, 96, 96, 3)).astype(np.float32)
+    labels = data.synthetic_batch(4, 20, 3, 3, seed=22)
+    np.savez(str(tmp_path / 'data.npz'), images=images, **{'l%d' % i: np.asarray(l) for i, l in enumerate(labels)})
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_shard_opt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+    for k in ('params', 'm', 'v'):
+        np.testing.assert_array_equal(r0['sh/' + k], r0['rep/' + k])
+        np.testing.assert_array_equal(r1['sh/' + k], r1['rep/' + k])
+        np.testing.assert_array_equal(r0['sh/' + k], r1['sh/' + k])
+    assert np.abs(r0['sh/m']).max() > 0
+    np.testing.assert_array_equal(r0['steps/params'], r1['steps/params'])
+    np.testing.assert_array_equal(r0['steps/m'], r1['steps/m'])
+    moved = np.abs(r0['steps/params'] - r0['p0']) > 0
+    assert moved.mean() > 0.5, moved.mean()              # Adam moves every parameter that has a gradient by ~lr per step

@@ -125,6 +125,77 @@ def test_grad_reducer_gloo_world2(tmp_path):
     assert open(out).read() == 'ok'
 
 
+def _shard_worker(rank, world, port, out, grad_dtype):
+    """Optimizer sharding on host tensors: reduce-scatter / update 1/world / all-gather per bucket == all-reduce + replicated update."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from yolo_tf_amd.parallel import GradReducer, init_distributed, shard_of
+    init_distributed(backend='gloo')
+    sizes = [4000, 2500, 70, 10000, 3640, 30, 129]          # a toy arena: variables on 64-element boundaries like engine.layout_params
+    offs, off = [], 0
+    for n in sizes:
+        offs.append((off, n))
+        off += (n + 63) // 64 * 64
+    bucket_mb = 3000 * 4 / (1024 * 1024)
+
+    def run(shard):
+        torch.manual_seed(5)
+        params = torch.randn(off)
+        m = torch.zeros(off)
+        grads = torch.empty(off)
+        red = GradReducer(grads, offs, bucket_mb=bucket_mb, grad_dtype=grad_dtype, shard_params=params if shard else None)
+        assert len(red.buckets) >= 3
+
+        def update(lo, hi):            # a stateful elementwise optimizer (momentum), like the kernels: touches [lo, hi) only
+            m[lo:hi].mul_(0.9).add_(grads[lo:hi] / world)
+            params[lo:hi].sub_(0.1 * m[lo:hi])
+        for step in range(3):
+            g = torch.Generator().manual_seed(100 * step + rank)
+            grads.copy_(torch.randn(off, generator=g))
+            red.begin()
+            red.update_fn = update
+            for end in sorted(o + (n + 63) // 64 * 64 for o, n in offs):
+                red.ready_upto(end)
+            if shard:
+                red.finish(wait=True)                       # chains ran inside ready_upto: exchange, shard update, gather
+            else:
+                red.finish(wait=False)
+                for lo, hi in red.completed_buckets():
+                    update(lo, hi)
+        if shard:
+            # slots are valid for the rank's own shards (+ the replicated remainders) until gathered
+            own = torch.zeros(off, dtype=torch.bool)
+            for s_, e_ in red.buckets:
+                lo, hi, send = shard_of(s_, e_, world, rank)
+                own[lo:hi] = True
+                own[send:e_] = True
+            red.gather_slots([m])
+        return params, m
+
+    p_rep, m_rep = run(False)
+    p_sh, m_sh = run(True)
+    assert torch.equal(p_sh, p_rep), (rank, float((p_sh - p_rep).abs().max()))        # bit-identical parameters (two ranks: a+b == b+a)
+    assert torch.equal(m_sh, m_rep)
+    gathered = [torch.empty_like(p_sh) for _ in range(world)]
+    dist.all_gather(gathered, p_sh)
+    assert all(torch.equal(gathered[0], t) for t in gathered)                         # replicas stay identical
+    lo, hi, send = shard_of(0, 1000, 2, rank)
+    assert (hi - lo) == 448 and send == 896 and lo == rank * 448                      # 1000 = 2 x 448 + a replicated remainder of 104
+    if rank == 0:
+        open(out, 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('grad_dtype', ['f32', 'bf16'])
+def test_optimizer_sharding_equals_replicated_update_gloo_world2(tmp_path, grad_dtype):
+    """[mi355x] shard_optimizer (parallel.GradReducer shard_params): after three steps the parameters and the (gathered) optimizer state are
+    bit-identical to the all-reduce + replicated-update path, on both ranks, with f32 and bf16 wire formats."""
+    out = str(tmp_path / 'ok')
+    mp.spawn(_shard_worker, args=(2, _free_port(), out, grad_dtype), nprocs=2, join=True)
+    assert open(out).read() == 'ok'
+
+
 def test_single_process_reducer_is_a_noop():
     from yolo_tf_amd.parallel import GradReducer
     g = torch.ones(100)

@@ -132,7 +132,8 @@ def main():
                            gradient_clip=args.gradient_clip, config=config, seed=seed, world_size=world,
                            bucket_mb=config.getfloat('mi355x', 'bucket_mb') if config.has_option('mi355x', 'bucket_mb') else 64.0,
                            grad_dtype=config.get('mi355x', 'grad_dtype') if config.has_option('mi355x', 'grad_dtype') else 'f32',
-                           sync_bn=config.getboolean('mi355x', 'sync_bn') if config.has_option('mi355x', 'sync_bn') else False)
+                           sync_bn=config.getboolean('mi355x', 'sync_bn') if config.has_option('mi355x', 'sync_bn') else False,
+                           shard_optimizer=config.getboolean('mi355x', 'shard_optimizer') if config.has_option('mi355x', 'shard_optimizer') else False)
     logging.warning('optimizer=%s, dtype=%s, world=%d, parameters=%d' % (args.optimizer, dtype, world, session.engine.n_params))
     # rank 0 alone chooses and reads the checkpoint; the others receive parameters, statistics, optimizer slots and
     # global_step from it (same seed -> same initial weights anyway, but a restore must not depend on what each rank sees)
@@ -222,9 +223,11 @@ def main():
                 raise FloatingPointError('total_loss is not finite (on at least one rank)')
             last_summary, t_rate, n_rate = now, time.time(), 0
         if want_save:
+            session.gather_optimizer_state()     # (optimizer sharding: every rank joins the all-gather of the slot shards; a no-op otherwise)
             if rank == 0:
                 logging.warning('saved ' + save())
             last_save = now
+    session.gather_optimizer_state()
     if rank == 0:
         logging.warning('saved ' + save())
         writer.close()

@@ -75,6 +75,26 @@ extern "C" int yolo2_comm_allreduce_bucket(yolo2_comm *comm, void *buf, long cou
     return YOLO2_COMM_OK;
 }
 
+// Optimizer sharding (parallel.GradReducer shard_params): buf holds world * shard_count elements; every rank keeps the sum over ranks of
+// ITS shard (elements [rank * shard_count, (rank + 1) * shard_count)) in place, the other shards are left as they were
+extern "C" int yolo2_comm_reduce_scatter_bucket(yolo2_comm *comm, void *buf, long shard_count, int dtype, void *stream) {
+    if (!comm || !buf || shard_count <= 0 || (dtype != YOLO2_COMM_F32 && dtype != YOLO2_COMM_BF16))
+        return fail(YOLO2_COMM_E_ARG, "yolo2_comm_reduce_scatter_bucket: comm / buf NULL, shard_count %ld <= 0, or dtype %d", shard_count, dtype);
+    const size_t esz = dtype == YOLO2_COMM_F32 ? 4 : 2;
+    char *own = (char *)buf + (size_t)comm->rank * (size_t)shard_count * esz;       // in place: recvbuff = sendbuff + rank * recvcount
+    COMM_RCCL(ncclReduceScatter(buf, own, (size_t)shard_count, dtype == YOLO2_COMM_F32 ? ncclFloat32 : ncclBfloat16, ncclSum, comm->nccl, (hipStream_t)stream),
+              "ncclReduceScatter");
+    return YOLO2_COMM_OK;
+}
+
+// ... and the way back: every rank's shard (updated parameters) becomes visible in every rank's buf
+extern "C" int yolo2_comm_allgather(yolo2_comm *comm, void *buf, long shard_bytes, void *stream) {
+    if (!comm || !buf || shard_bytes <= 0) return fail(YOLO2_COMM_E_ARG, "yolo2_comm_allgather: comm / buf NULL or shard_bytes %ld <= 0", shard_bytes);
+    const char *own = (const char *)buf + (size_t)comm->rank * (size_t)shard_bytes;  // in place: sendbuff = recvbuff + rank * sendcount
+    COMM_RCCL(ncclAllGather(own, buf, (size_t)shard_bytes, ncclUint8, comm->nccl, (hipStream_t)stream), "ncclAllGather");
+    return YOLO2_COMM_OK;
+}
+
 extern "C" int yolo2_comm_broadcast(yolo2_comm *comm, void *buf, long bytes, int root, void *stream) {
     if (!comm || !buf || bytes <= 0 || root < 0 || root >= comm->world)
         return fail(YOLO2_COMM_E_ARG, "yolo2_comm_broadcast: comm / buf NULL, bytes %ld <= 0, or root %d", bytes, root);

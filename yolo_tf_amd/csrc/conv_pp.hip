@@ -75,6 +75,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     constexpr bool SKIPIDLE = (SCHED & 8) != 0, PRIO = (SCHED & 16) != 0;
     // timing ablations (wrong results by design; scripts/pp_sweep.py): +64 no MFMAs, +128 no fragment reads, +256 no DMA inside the K loop
     constexpr bool A_NOMFMA = (SCHED & 64) != 0, A_NOREAD = (SCHED & 128) != 0, A_NODMA = (SCHED & 256) != 0;
+    constexpr bool A_NOEPI = (SCHED & 512) != 0, A_NOHANDOFF = (SCHED & 1024) != 0;      // +512 no epilogue (stores, statistics), +1024 no stream-K hand-off traffic
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
     // (ORDER 4 issues the halo piece half a step later; ORDER 5 reads the next chunk's halo one step earlier: one slot less each)
     static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + ((ORDER == 4 || ORDER == 5) ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         constexpr int SLOT = BM * BN;
         const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
         const unsigned slot_lane = (unsigned)(((size_t)wave_e * (TM * TN * 16 * 64) + (size_t)lane_e * 4) * sizeof(float));
-        if (kt_beg > 0) {
+        if (A_NOHANDOFF) { if (kt_beg > 0) continue; }
+        else if (kt_beg > 0) {
             const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
         }
-        if (kt_end < nk) {
+        if (!A_NOHANDOFF && kt_end < nk) {
             const long tile_end = su - kt_end + nk;
             long covered = su;
             for (int p = wx + 1; covered < tile_end; ++p) {
@@ -472,6 +474,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         }
     }
 
+    if (A_NOEPI) {       // (ablation: keep the accumulators alive, store nothing)
+        if (acc[0][0][0] == 123.456f && acc[1][1][5] == 1.0f) O[0] = (bf16)acc[0][1][3];
+        continue;
+    }
     // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave_e LDS image, 16-byte stores), with the
     // forward statistics or the producer layer's BN-backward sums taken from the rounded values
     {
@@ -626,6 +632,8 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         switch (sched) {
             Y2P_ABL_CASE(6 + 64) Y2P_ABL_CASE(6 + 128) Y2P_ABL_CASE(6 + 256) Y2P_ABL_CASE(6 + 64 + 128) Y2P_ABL_CASE(6 + 128 + 256) Y2P_ABL_CASE(6 + 64 + 128 + 256)
             Y2P_ABL_CASE(6 + 64 + 256)
+            Y2P_ABL_CASE(2 + 64 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 1024) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512 + 1024)
+            Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024)
             default: return 1;
         }
     }

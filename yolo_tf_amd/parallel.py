@@ -72,9 +72,26 @@ def make_buckets(offsets_sizes, total, bucket_elems):
     return buckets
 
 
+def shard_of(s, e, world, rank, align=64):
+    """Optimizer sharding of the bucket [s, e): ``world`` equal shards of L = floor((e - s) / (world * align)) * align elements (what
+    reduce-scatter / all-gather need) followed by a remainder of fewer than world * align elements that stays replicated.
+    -> (own_lo, own_hi, sharded_end): this rank updates [own_lo, own_hi) and the remainder [sharded_end, e)."""
+    L = ((e - s) // (world * align)) * align
+    return s + rank * L, s + (rank + 1) * L, s + world * L
+
+
 class GradReducer(object):
-    def __init__(self, grads, offsets_sizes, bucket_mb=64.0, group=None, always_reduce=False, grad_dtype='f32', timing=False):
+    def __init__(self, grads, offsets_sizes, bucket_mb=64.0, group=None, always_reduce=False, grad_dtype='f32', timing=False,
+                 shard_params=None, rank=None):
         """``always_reduce``: issue the collectives even in a one-rank group (RCCL smoke tests on a single GPU).
+        ``shard_params`` (the flat parameter arena; [mi355x] shard_optimizer): optimizer sharding.  A bucket is then reduce-SCATTERED, this
+        rank updates its 1/world shard through ``update_fn(lo, hi)`` (set by the session before backward: the optimizer kernel over a
+        slice of the arenas) and the updated parameters are all-gathered -- all three on the communication stream, bucket by bucket while
+        backward is still running on earlier layers.  The replicated optimizer pass (1.9 GB of HBM traffic per rank and step, the same on
+        every rank) shrinks to 1/world of it; the wire carries the same bytes as the all-reduce it replaces (ring all-reduce = reduce-
+        scatter + all-gather).  Master parameters are only read by the next forward's operand preparation, so updating the late layers'
+        parameters while the early layers' backward runs is safe; optimizer slots are valid for a rank's own shards only
+        (``gather_slots`` before a checkpoint).
         ``grad_dtype`` 'bf16': a bucket is rounded to bf16 into a wire buffer, all-reduced there and widened back into the f32 arena --
         half the bytes per link (134 MB instead of 269 MB per step and rank); the sum over ranks is then formed in bf16 by
         the collective, which costs ~3 significant digits of the SUMMED gradient (Adam normalises its scale away; the default stays f32).
@@ -97,6 +114,10 @@ class GradReducer(object):
         self.handles = []
         self.pending_events = []
         self.done_events = []
+        self.params = shard_params
+        self.shard = shard_params is not None
+        self.rank = (dist.get_rank(group) if dist.is_initialized() else 0) if rank is None else rank
+        self.update_fn = None
 
     def begin(self):
         self.next_bucket = 0
@@ -118,8 +139,98 @@ class GradReducer(object):
             self._launch(s, e)
             self.next_bucket += 1
 
+    # ---- optimizer sharding: reduce-scatter -> update own shard -> all-gather, per bucket
+    def _reduce_scatter(self, buf, s, own_lo, own_hi, send):
+        """buf[own_lo:own_hi] = sum over ranks of their buf[own_lo:own_hi]; [s, send) = world equal shards.  In place (the output is this
+        rank's slice of the input).  Backends without reduce-scatter (gloo, the CPU tests) all-reduce the range: same values."""
+        if send == s:
+            return
+        try:
+            dist.reduce_scatter_tensor(buf[own_lo:own_hi], buf[s:send], op=dist.ReduceOp.SUM, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_reduce(buf[s:send], op=dist.ReduceOp.SUM, group=self.group)
+
+    def _all_gather(self, buf, s, own_lo, own_hi, send):
+        if send == s:
+            return
+        try:
+            dist.all_gather_into_tensor(buf[s:send], buf[own_lo:own_hi], group=self.group)
+        except (RuntimeError, NotImplementedError):
+            # gloo (tests): no all-gather into one tensor, none at all for device tensors -- sum of zero-padded shards instead
+            tmp = torch.zeros_like(buf[s:send])
+            tmp[own_lo - s:own_hi - s].copy_(buf[own_lo:own_hi])
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+            buf[s:send].copy_(tmp)
+
+    def _sharded_chain(self, s, e):
+        """On the current stream (the communication stream on a GPU): exchange, update, gather of one bucket."""
+        from . import ops
+        world = dist.get_world_size(self.group)
+        own_lo, own_hi, send = shard_of(s, e, world, self.rank)
+        g = self.grads
+        if self.wire is not None and g.is_cuda:
+            ops.cast_f32_bf16(g[s:e], self.wire[s:e], e - s)
+            self._reduce_scatter(self.wire, s, own_lo, own_hi, send)
+            if send < e:
+                dist.all_reduce(self.wire[send:e], op=dist.ReduceOp.SUM, group=self.group)
+            if own_hi > own_lo:
+                ops.cast_bf16_f32(self.wire[own_lo:own_hi], g[own_lo:own_hi], own_hi - own_lo)
+            if send < e:
+                ops.cast_bf16_f32(self.wire[send:e], g[send:e], e - send)
+        else:
+            if self.wire is not None:          # host tensors: torch's converting copies stand in for the cast kernels
+                self.wire[s:e].copy_(g[s:e])
+                self._reduce_scatter(self.wire, s, own_lo, own_hi, send)
+                if send < e:
+                    dist.all_reduce(self.wire[send:e], op=dist.ReduceOp.SUM, group=self.group)
+                g[own_lo:own_hi].copy_(self.wire[own_lo:own_hi])
+                g[send:e].copy_(self.wire[send:e])
+            else:
+                self._reduce_scatter(g, s, own_lo, own_hi, send)
+                if send < e:
+                    dist.all_reduce(g[send:e], op=dist.ReduceOp.SUM, group=self.group)
+        assert self.update_fn is not None, 'optimizer sharding: the session sets update_fn before backward'
+        if own_hi > own_lo:
+            self.update_fn(own_lo, own_hi)
+        if send < e:
+            self.update_fn(send, e)             # (the replicated remainder: < world * 64 elements)
+        self._all_gather(self.params, s, own_lo, own_hi, send)
+
+    def gather_slots(self, slots):
+        """Optimizer sharding: every rank holds valid optimizer state for its own shards only; before a checkpoint (or a switch back to
+        the replicated update) the shards of every slot arena are all-gathered so that each rank holds the complete state."""
+        if not self.shard or self.world == 1 or not dist.is_initialized():
+            return
+        world = dist.get_world_size(self.group)
+        for s, e in self.buckets:
+            own_lo, own_hi, send = shard_of(s, e, world, self.rank)
+            for slot in slots:
+                self._all_gather(slot, s, own_lo, own_hi, send)
+
     def _launch(self, s, e):
         view = self.grads[s:e]
+        if self.shard:
+            if self.use_stream:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm_stream.wait_event(ev)
+                for pe in self.pending_events:
+                    self.comm_stream.wait_event(pe)
+                self.pending_events = []
+                with torch.cuda.stream(self.comm_stream):
+                    if self.timing:
+                        start = torch.cuda.Event(enable_timing=True)
+                        start.record(self.comm_stream)
+                    self._sharded_chain(s, e)
+                    done = torch.cuda.Event(enable_timing=self.timing)
+                    done.record(self.comm_stream)
+                self.done_events.append(done)
+                if self.timing:
+                    self.timed.append([start, done, None, (e - s) * (2 if self.wire is not None else 4) + (e - s) * 4])
+            else:
+                self._sharded_chain(s, e)
+                self.handles.append((None, s, e))
+            return
         if self.use_stream:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())

@@ -24,7 +24,7 @@ class TrainSession(object):
 
     def __init__(self, builder, batch_size, dtype='bf16', optimizer='adam', learning_rate=1e-6, gradient_clip=0.0,
                  config=None, seed=0, world_size=1, bucket_mb=64.0, preprocess_mode=0, sizes=None, grad_dtype='f32', comm_cus=None, comm_timing=False,
-                 sync_bn=False):
+                 sync_bn=False, shard_optimizer=False):
         """``sizes``: optional list of (width, height) input sizes for multi-scale training (BASELINE configs[3]); buffers are
         allocated once for the largest, ``set_size`` switches between them, the builder's configured size is selected first."""
         assert builder.training, 'call builder(data, training=True) first'
@@ -69,7 +69,11 @@ class TrainSession(object):
         self.global_step = 0
         self.world_size = world_size
         self.preprocess_mode = preprocess_mode
-        self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb, grad_dtype=grad_dtype, timing=comm_timing) if world_size > 1 else None
+        # [mi355x] shard_optimizer: reduce-scatter / update 1/world / all-gather instead of all-reduce + the replicated optimizer pass
+        # (parallel.GradReducer); per-tensor clipping needs every complete gradient first, so it keeps the replicated form
+        self.shard_optimizer = bool(shard_optimizer) and world_size > 1 and self.gradient_clip <= 0
+        self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb, grad_dtype=grad_dtype, timing=comm_timing,
+                                   shard_params=e.params if self.shard_optimizer else None) if world_size > 1 else None
         if world_size > 1:
             # the collectives' persistent kernels hold CUs for their whole duration: stream-K launches (one workgroup per CU) are sized
             # for what is left ([mi355x] comm_cus, default 32 -- an RCCL ring's channel count on this part)
@@ -116,6 +120,13 @@ class TrainSession(object):
             self._objectives_pending = (m.cell_height, m.cell_width)
         if self.reducer is not None:
             self.reducer.begin()
+            # optimizer sharding only inside step(): a bare forward_backward() promises complete (all-reduced) gradients and no update
+            self.reducer.shard = self.shard_optimizer and defer_collectives
+            self._sharded_pending = self.reducer.shard
+            if self.reducer.shard:
+                # the update of a bucket's shard runs inside the bucket's chain on the communication stream, while backward continues
+                lr, t, gs = self.lr_fn(self.global_step), self.global_step + 1, 1.0 / self.world_size
+                self.reducer.update_fn = lambda lo, hi: self.optimizer.apply(e.params, e.grads, lr, t, gs, lo, hi)
             e.backward(on_layer_done=lambda op, ev: self.reducer.ready_upto(self._layer_end[op['name']], ev))
             # without clipping the optimizer consumes the buckets as they arrive (apply_gradients); clipping needs them all
             self._deferred = defer_collectives and self.gradient_clip <= 0 and self.bucketed_update
@@ -134,7 +145,14 @@ class TrainSession(object):
         else:
             gscale = 1.0 / self.world_size
         lr = self.lr_fn(self.global_step)
-        if self.reducer is not None and getattr(self, '_deferred', False):
+        if self.reducer is not None and getattr(self, '_sharded_pending', False):
+            # the buckets' chains (reduce-scatter, shard update, all-gather) were enqueued during backward: wait for the last of them
+            self.reducer.finish(wait=True)
+            self._deferred = False
+            self._sharded_pending = False
+            self.global_step += 1
+            e._filters_dirty = True
+        elif self.reducer is not None and getattr(self, '_deferred', False):
             # data parallel: update bucket k while the all-reduces of buckets k+1.. are still in flight -- only the last
             # (smallest: the early layers) bucket's collective is exposed, and the 1.9 GB optimizer pass hides the rest
             for lo, hi in self.reducer.completed_buckets():
@@ -150,6 +168,13 @@ class TrainSession(object):
             self.optimizer.apply(e.params, e.grads, lr, self.global_step + 1, gscale)
             self.global_step += 1
             e._filters_dirty = True
+
+    def gather_optimizer_state(self):
+        """With optimizer sharding every rank holds valid optimizer slots for its own shards only: all-gathers them (collective: every rank
+        calls it) so that the rank that writes the checkpoint has the complete state.  No-op for the replicated update."""
+        if self.reducer is not None and self.shard_optimizer:
+            self.reducer.shard = True
+            self.reducer.gather_slots(self.optimizer.slots)
 
     def step(self, images, labels=None):
         if labels is not None:
