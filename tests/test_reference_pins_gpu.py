@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 # max |got - ref| / max |ref| of the whole-network f32 logits against the fixtures made by executing the reference's source (tests/golden);
 # the fixtures' convolutions are evaluated in f64 and rounded once per layer, so the whole figure is this engine's own f32 error
-INFER_TOL = 2e-4
-TRAIN_TOL = 5e-4
+# Measured (profiles/r04_pp5_pins.txt): inference 1.1e-6 .. 1.9e-6, training mode 1.8e-5 .. 2.5e-5 -- north_star's 1e-4 holds end to end with a margin
+INFER_TOL = 2e-5
+TRAIN_TOL = 1e-4
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'golden'))
 import seeded   # noqa: E402
@@ -135,7 +136,7 @@ def test_engine_logits_vs_reference_source(golden_dir, key, inference, names):
         assert_close(got, ref, INFER_TOL, 'logits (fold_bn=%s)' % fold)
 
 
-TRAIN_CASES = [('yolo2_darknet', 'darknet', 20, 5e-4),             # 64x64: 2x2 cells x batch 2 = 8 samples per channel in the last stages
+TRAIN_CASES = [('yolo2_darknet', 'darknet', 20, TRAIN_TOL),        # 64x64: 2x2 cells x batch 2 = 8 samples per channel in the last stages
                ('yolo2_darknet_t128', 'darknet', 20, TRAIN_TOL), ('yolo2_darknet_coco_t128', 'darknet', 80, TRAIN_TOL), ('yolo2__darknet_t128', '_darknet', 20, TRAIN_TOL)]
 
 
