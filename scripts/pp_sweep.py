@@ -92,4 +92,4 @@ for name, H, cin, cout in LAYERS:
     for what in rows:
         print('%-7s %-9s %s' % (name, what, '   '.join(rows[what])), flush=True)
 ops.set_igemm_tap(2)
-ops.set_pp(grid=0, dmapos=-1, min_steps=18, min_share=26)
+ops.set_pp(grid=0, dmapos=-1, min_steps=18, min_share=24)

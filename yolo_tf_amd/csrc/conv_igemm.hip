@@ -726,7 +726,7 @@ extern "C" int yolo2_debug_set_igemm_tap(int mode) {
 static std::atomic<int> g_pp_grid{0};
 static std::atomic<int> g_pp_dmapos{2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
 static std::atomic<long> g_pp_min_steps{18};
-static std::atomic<long> g_pp_min_share{26};
+static std::atomic<long> g_pp_min_share{24};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
     if (grid != -1) g_pp_grid.store(grid, std::memory_order_relaxed);
     if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
@@ -788,8 +788,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
         // (profiles/r04_pp2_*.txt, r04_pp3_*.txt, batch 16 and 8):
         //   * a tile grid that gives 60-100 % of the CUs one whole tile each: one workgroup per tile, no hand-off (26x26 256->512 forward
         //     30.8 vs 35.1 us; 52x52 data gradients 31 vs 36.5 us);
-        //   * else stream-K over one workgroup per CU when a workgroup's share is >= 26 K steps (the >= 1024-channel 13x13 layers:
-        //     56 vs 60 us, 129 vs 144 us; the 512-channel ones, 24.75 steps per workgroup, stay with the per-tap kernels);
+        //   * else stream-K over one workgroup per CU when a workgroup's share is >= 24 K steps and a tile is cut into at most four shares
+        //     (the owner adds its partners' parked partials one after the other: the 13x13 512 -> 1024 forward, 88 tiles, 38.9 vs 41.0 us;
+        //     its data gradient, 44 tiles of the same 24.75 steps per workgroup, 42.4 vs 41.1 us: per-tap; >= 1024-channel 13x13 layers
+        //     55 vs 60-75 us, 126 vs 144-181 us);
         //   * a data gradient that also reduces the producer's BN-backward sums takes it from 10 steps per workgroup when it has >= 8192
         //     pixels: the per-tap kernels' form of that epilogue costs 12-30 us there, this one 4-7.
         if (tap_mode != 0 && ksize == 3 && Cp % 64 == 0 && W <= 55 && Nf > 64 && wide_store && ws && tu.stream &&
@@ -803,7 +805,8 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             else if (gm >= 8) grid = (can_stream && gm <= tu.cus) ? gm : 0;                  // explicit workgroup count (sweeps)
             else if (gm <= -2) grid = (can_stream && tiles_t * -gm <= tu.cus) ? (int)(tiles_t * -gm) : 0;      // -P: every tile cut into exactly P shares
             else if (tiles_t * 10 >= (long)tu.cus * 6 && tiles_t <= tu.cus) grid = (int)tiles_t;
-            else if (can_stream && (units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus || (bz.Y && M >= 8192 && units_p >= 10L * tu.cus))) grid = tu.cus;
+            else if (can_stream && ((units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus && tiles_t * 4 >= tu.cus) ||
+                                    (bz.Y && M >= 8192 && units_p >= 10L * tu.cus))) grid = tu.cus;
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];

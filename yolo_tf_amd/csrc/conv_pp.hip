@@ -56,10 +56,10 @@ constexpr int y2p_leave(int order, int D, int tp, int hslots, bool skipidle) {
 //   0  DMA pieces, then the fragment reads                       1  all pieces behind the first four MFMAs of the MFMA phase
 //   2  fragment reads, then the pieces (issued under the reads' latency)      3  reads, lgkmcnt(0), then the pieces (read-free gap)
 //   4  reads + the two filter pieces in the LOAD phase, the halo piece behind the first four MFMAs
-//   5  as 2, but the pixel (A) fragments of step s+1 are read behind the MFMAs of step s, each 16-k group into the registers its four
-//      MFMAs have just released: the LOAD phase keeps the eight filter reads + the pieces and becomes shorter than the MFMA phase
-//   6  NO ping-pong: all eight waves in the same step, one barrier per step; the fragments of step s+1 (pixels and filters) are read
-//      behind the MFMAs of step s, each 16-k group into the registers its four MFMAs have just released
+//   (5 = as 2 with the pixel fragments of step s+1 read behind the MFMAs of step s, and 6 = no ping-pong at all, one barrier per step with
+//    every fragment read trailing the MFMAs that release its registers, were built and measured: conv20 forward 137 and 147 us against 129 for
+//    order 2 -- any read or DMA instruction inside a wave's MFMA stream delays its next MFMA -- profiles/r04_pp3_b16.txt, r04_pp5_b16.txt;
+//    the code is in the history of this file)
 //   +8  slots of taps >= HSLOTS carry no halo piece at all (2 instead of 3 instructions; the counted waits use the exact per-tap sums)
 //   +16 s_setprio 1 for the MFMA phase
 template <bool BNBWD, int HROWS, int NSB, int SCHED>
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     constexpr bool A_NOMFMA = (SCHED & 64) != 0, A_NOREAD = (SCHED & 128) != 0, A_NODMA = (SCHED & 256) != 0;
     constexpr bool A_NOEPI = (SCHED & 512) != 0, A_NOHANDOFF = (SCHED & 1024) != 0;      // +512 no epilogue (stores, statistics), +1024 no stream-K hand-off traffic
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
-    // (ORDER 4 issues the halo piece half a step later; ORDER 5 reads the next chunk's halo one step earlier: one slot less each)
-    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + ((ORDER == 4 || ORDER == 5) ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
+    // (ORDER 4 issues the halo piece half a step later: one slot less)
+    static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + (ORDER == 4 ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[RING + NSB * Y2P_BBYTES];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,6 +105,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     typedef __attribute__((address_space(3))) void *lds_void_ptr;
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
 
+  bool park_pending = false;
   for (bool first_seg = true;; first_seg = false) {
     if (su >= su_end) break;
     const int t = (int)(su / nk);
@@ -145,61 +146,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         const int r = br0 + 8 * i;
         b_voff[i] = (unsigned)(n0 + r) * (unsigned)(TAPS * Cp) * 2u + (unsigned)(((lane_s & 7) ^ ((r >> 1) & 7)) * 16);
     }
-    // which of the nine taps of this lane_s's two fragment rows lie inside the image
-    unsigned amask = 0;                                  // 9 bits per fragment row, row i at bit 16 * i
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * (TM * 32) + i * 32 + frow_s;
-        unsigned mask = 0;
-        if (m < M) {
-            const int HW = H * W;
-            int bq = (int)((double)m * rcp_hw);
-            int rem = m - bq * HW;
-            if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
-            int h = (int)((float)rem * rcp_w);
-            int w = rem - h * W;
-            if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
-            const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
-            mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
-        }
-        amask |= mask << (16 * i);
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- LDS read addresses.  A: one per (tap, fragment row), valid for the halo buffer of the current chunk parity; the 16-k group
-    // kk is XORed in (bits 5-6 come from the swizzle term alone: every other summand is a multiple of 128).  B: one per 16-k group.
-    const unsigned lds0 = y2_lds_addr(smem);
-    const unsigned hi16 = (unsigned)(lane_s >> 5) << 4;
     const int c_first = kt_beg / TAPS;
-    unsigned aaddr[TAPS][TM];
-#pragma unroll
-    for (int tp = 0; tp < TAPS; ++tp) {
-        const int dh = tp / 3 - 1, dw = tp % 3 - 1;
-        const unsigned toffb = (unsigned)(((W + 1) + dh * W + dw) * ROWB);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned hb = (unsigned)((wm * (TM * 32) + i * 32 + frow_s) * ROWB) + toffb;      // halo row * 128
-            const bool ok = ((amask >> (16 * i + tp)) & 1u) != 0u;
-            const unsigned sw = ((hb >> 4) & 0x70u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane_s's half of the k group
-            // masked (pixel, tap): the buffer's zero KiB, at the same offset inside a 256-byte bank line as the real row
-            aaddr[tp][i] = lds0 + (unsigned)((c_first & 1) * HB) + (ok ? hb : (unsigned)HBYTES + (hb & 0x80u)) + sw;
-        }
-    }
-    unsigned baddr[4];
-    {
-        const unsigned brow = lds0 + (unsigned)(RING + (wn * TN * 32 + frow_s) * ROWB);
-        const unsigned bx = hi16 ^ ((unsigned)((frow_s >> 1) & 7) << 4);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) baddr[kk] = brow + (bx ^ (unsigned)(kk * 32));
-    }
-
     // one DMA slot: halo piece `hs` of chunk `hc` (or an idle write into the zero KiB) + the filter tile of K step `kb` into ring stage `bstage`
     auto issue_halo = [&](int hs, int hc, int hc_mem, bool hreal) {
         const bool real = hreal && hs * NW + wave < HPIECES;
@@ -245,10 +192,74 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             issue_halo(0, 0, 0, false);
         }
     }
+    // ---- per-lane index arithmetic (f64 reciprocal pixel decode, 18 read addresses), under the latency of the prologue's DMA
+    // which of the nine taps of this lane_s's two fragment rows lie inside the image
+    unsigned amask = 0;                                  // 9 bits per fragment row, row i at bit 16 * i
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * (TM * 32) + i * 32 + frow_s;
+        unsigned mask = 0;
+        if (m < M) {
+            const int HW = H * W;
+            int bq = (int)((double)m * rcp_hw);
+            int rem = m - bq * HW;
+            if (rem < 0) rem += HW; else if (rem >= HW) rem -= HW;
+            int h = (int)((float)rem * rcp_w);
+            int w = rem - h * W;
+            if (w < 0) { w += W; --h; } else if (w >= W) { w -= W; ++h; }
+            const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+            mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
+        }
+        amask |= mask << (16 * i);
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- LDS read addresses.  A: one per (tap, fragment row), valid for the halo buffer of the current chunk parity; the 16-k group
+    // kk is XORed in (bits 5-6 come from the swizzle term alone: every other summand is a multiple of 128).  B: one per 16-k group.
+    const unsigned lds0 = y2_lds_addr(smem);
+    const unsigned hi16 = (unsigned)(lane_s >> 5) << 4;
+    unsigned aaddr[TAPS][TM];
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp) {
+        const int dh = tp / 3 - 1, dw = tp % 3 - 1;
+        const unsigned toffb = (unsigned)(((W + 1) + dh * W + dw) * ROWB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned hb = (unsigned)((wm * (TM * 32) + i * 32 + frow_s) * ROWB) + toffb;      // halo row * 128
+            const bool ok = ((amask >> (16 * i + tp)) & 1u) != 0u;
+            const unsigned sw = ((hb >> 4) & 0x70u) ^ hi16;           // ((row >> 1) & 7) << 4, folded with this lane_s's half of the k group
+            // masked (pixel, tap): the buffer's zero KiB, at the same offset inside a 256-byte bank line as the real row
+            aaddr[tp][i] = lds0 + (unsigned)((c_first & 1) * HB) + (ok ? hb : (unsigned)HBYTES + (hb & 0x80u)) + sw;
+        }
+    }
+    unsigned baddr[4];
+    {
+        const unsigned brow = lds0 + (unsigned)(RING + (wn * TN * 32 + frow_s) * ROWB);
+        const unsigned bx = hi16 ^ ((unsigned)((frow_s >> 1) & 7) << 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) baddr[kk] = brow + (bx ^ (unsigned)(kk * 32));
+    }
+
+    if (park_pending) {
+        // The tail segment this workgroup ran before this one parked its partial tile with write-through stores and came straight here:
+        // their acknowledgement latency ran under this prologue's address arithmetic and DMA issue.  vmcnt(0), not a counted wait: loads
+        // and stores share the counter and only "everything older has completed" is certain for a mix of the two.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        park_pending = false;
+    }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (ORDER != 6 && wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
+    if (wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
     __builtin_amdgcn_sched_barrier(0);
 
     bf16x8 fa[4][TM], fb[4][TN];
@@ -278,69 +289,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 auto dma_halo = [&]() { if (has_halo && !A_NODMA) issue_halo(tp, c + 1, mc1, tp < HSLOTS && next_ok); };
                 // DMA instructions this wave may leave in flight at the end of LOAD(tp): everything issued after its pieces of step kt+1
                 constexpr int LEAVE = y2p_leave(ORDER, D, tp, HSLOTS, SKIPIDLE);
-                if constexpr (ORDER == 6) {
-                    // ---- single-phase software pipeline (no ping-pong): all eight waves run the same step; a step's MFMAs use fragments read
-                    // during the previous step, and each 16-k group's registers are refilled with the NEXT step's fragments right behind the four
-                    // MFMAs that released them.  Both waves of a SIMD feed the matrix pipe, covering each other's read / DMA issue bubbles.
-                    const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
-                    if (kt == kt_beg && !A_NOREAD) {                   // first step of the segment: nobody has read its fragments yet
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
-                            const unsigned bb = baddr[kk] + so;
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // this wave's pieces of step kt+1 have landed: of the D-1 slots issued so far beyond step kt, the newest D-2 stay in flight
-                    if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(y2p_leave(1, D, tp, HSLOTS, SKIPIDLE)) : "memory");
-                    __builtin_amdgcn_s_barrier();          // ... for every wave; and nobody reads the ring stage of step kt-1 any more
-                    __builtin_amdgcn_sched_barrier(0);
-                    dma_halo();
-                    dma_filter();
-                    __builtin_amdgcn_sched_barrier(0);
-                    const bool pre = !A_NOREAD && kt + 1 < kt_end;
-                    const unsigned so1 = (unsigned)((stage_r == NSB - 1 ? 0 : stage_r + 1) * Y2P_BBYTES);
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                if (!A_NOMFMA) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        // Every read of the previous step has long returned here (its last group was issued a barrier, three DMA pieces and four
-                        // MFMAs ago).  Saying so through the builtin keeps hipcc's wait insertion exact: without it, it counts those sixteen
-                        // reads as outstanding and puts lgkmcnt(5) / lgkmcnt(1) before the later MFMA groups -- which wait for THIS step's
-                        // trailing reads.
-                        if (kk == 0) __builtin_amdgcn_s_waitcnt(0xc07f);
-                        if (pre) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[(tp + 1) % TAPS][i] ^ (unsigned)(kk * 32));
-                            const unsigned bb = baddr[kk] + so1;
-#pragma unroll
-                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    ++kt;
-                    stage_r = stage_r == NSB - 1 ? 0 : stage_r + 1;
-                    stage_i = stage_i == NSB - 1 ? 0 : stage_i + 1;
-                } else {
                 // ---- LOAD phase
                 if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
                 if (!A_NOREAD) {
-                    // ORDER 5: the pixel fragments of this step were read behind the MFMAs of the previous one (below) -- except for the
-                    // first step of a segment; the LOAD phase then carries the eight filter fragment reads only
-                    if (ORDER != 5 || kt == kt_beg) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
+                    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
-                    }
+                        for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
                         const unsigned bb = baddr[kk] + so;
@@ -350,7 +306,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ORDER == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ORDER == 2 || ORDER == 3 || ORDER == 5) { dma_halo(); dma_filter(); }
+                if (ORDER == 2 || ORDER == 3) { dma_halo(); dma_filter(); }
                 if (ORDER == 4) dma_filter();
                 __builtin_amdgcn_sched_barrier(0);
                 // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
@@ -367,7 +323,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- MFMA phase: registers only
                 if (PRIO) __builtin_amdgcn_s_setprio(1);
-                const bool pre_a = ORDER == 5 && !A_NOREAD && kt + 1 < kt_end;       // a next step exists in this segment: fetch its pixel fragments here
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -380,17 +335,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                         if (ORDER == 1) { dma_halo(); dma_filter(); } else dma_halo();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (ORDER == 5) {
-                        // the four MFMAs above were the last readers of fa[kk]: refill it with the NEXT step's 16-k group (tap tp+1; tap 0 of the
-                        // next chunk after tap 8: its addresses already point at the other halo buffer, whose pieces every wave waited for by the
-                        // end of LOAD(tap 7)).  The reads return during the next LOAD phase, whose lgkmcnt(0) covers them.
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (pre_a) {
-#pragma unroll
-                            for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[(tp + 1) % TAPS][i] ^ (unsigned)(kk * 32));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
                 if (PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -399,7 +343,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 ++kt;
                 stage_r = stage_r == NSB - 1 ? 0 : stage_r + 1;
                 stage_i = stage_i == NSB - 1 ? 0 : stage_i + 1;
-                }
             }
             // the next chunk reads the other halo buffer (every tap's addresses move, whether or not this segment ran the tap)
 #pragma unroll
@@ -416,7 +359,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         step(std::integral_constant<int, 8>{});
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (ORDER != 6 && wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
+    if (wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
     __builtin_amdgcn_sched_barrier(0);
 
     // Everything below indexes by (lane_e, wave_e): copies the compiler cannot see through, so that none of the hand-off / epilogue
@@ -442,9 +385,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                         const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcS, mine + ((i * TN + j) * 4 + q4) * 1024, 0, 16);
                     }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (BNBWD) {
+                // (the BN-backward instantiation publishes at once: with the deferred form below hipcc's allocation of its 245 registers spills)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                // published -- stores acknowledged, flag raised -- from inside the next segment's prologue, or after the loop when this was the
+                // workgroup's only segment
+                park_pending = true;
+            }
             continue;
         }
         if (!A_NOHANDOFF && kt_end < nk) {
@@ -496,44 +446,61 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
             }
         };
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write zeros into ring stages / the zero KiB)
-        __syncthreads();                                      // every wave_e has finished reading the last step's operands
-        unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
-        const bool tail = m0 + BM > M;
+        // per-column constants of both accumulator columns, requested before the drain below (their latency runs under it)
+        float bvj[TN], shj[TN];
+        bool nokj[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
-            const bool n_ok = n < Nf;
-            const float bv = (bias && n_ok) ? bias[n] : 0.f;
-            const float sh = (stats && n_ok) ? bn_shift[n] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
+            nokj[j] = n < Nf;
+            bvj[j] = (bias && nokj[j]) ? bias[n] : 0.f;
+            shj[j] = (stats && nokj[j]) ? bn_shift[n] : 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write zeros into ring stages / the zero KiB)
+        __syncthreads();                                      // every wave has finished reading the last step's operands
+        unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
+        const bool tail = m0 + BM > M;
+        // Staging: rounded tile into this wave's LDS image (+ the statistics of the rounded values).  Two copies of the 64-element loop,
+        // chosen by ONE uniform branch: the leaky ReLU of a BN-folded inference layer and the row test of the last pixel tile each cost
+        // two to three VALU per element when they are tested inside it (~10 % of the ~7 us a tile's epilogue takes).
+        auto stage_tile = [&](auto act_tag, auto tail_tag) {
+            constexpr bool ACT = decltype(act_tag)::value, TAIL = decltype(tail_tag)::value;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j) {
+                const float bv = bvj[j], sh = shj[j];
+                float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = i * 32 + 4 * (lane_e >> 5) + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bv;
-                    if (act_alpha != 1.0f) v = fmaxf(v, act_alpha * v);
-                    const T o = (T)v;
-                    *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane_e & 31)) * 2) = o;
-                    if (stats && (!tail || m0 + wm_e * WROWS + row < M)) {
-                        const float d = (float)o - sh;
-                        s1 += d;
-                        s2 += d * d;
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + 4 * (lane_e >> 5) + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r] + bv;
+                        if (ACT) v = fmaxf(v, act_alpha * v);
+                        const T o = (T)v;
+                        *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane_e & 31)) * 2) = o;
+                        if (stats && (!TAIL || m0 + wm_e * WROWS + row < M)) {
+                            const float d = (float)o - sh;
+                            s1 += d;
+                            s2 += d * d;
+                        }
+                    }
+                }
+                if (stats) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lane_e < 32 && nokj[j]) {
+                        const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
+                        const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                        float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
+                        if (stats_unique) { *p1 = s1; *p2 = s2; }
+                        else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
                     }
                 }
             }
-            if (stats) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lane_e < 32 && n_ok) {
-                    const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                    float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
-                    if (stats_unique) { *p1 = s1; *p2 = s2; }
-                    else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
-                }
-            }
-        }
+        };
+        if (act_alpha != 1.0f) { if (tail) stage_tile(std::true_type{}, std::true_type{}); else stage_tile(std::true_type{}, std::false_type{}); }
+        else if (tail) stage_tile(std::false_type{}, std::true_type{});
+        else stage_tile(std::false_type{}, std::false_type{});
         if (bstats) {
             bz_load_y(0);
             // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
@@ -606,6 +573,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         }
     }
   }
+  if (park_pending) {       // the parked tail was this workgroup's last segment
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Launch (called by conv_igemm.hip launch_conv once it has decided that the shape takes this kernel): `grid` workgroups share the
@@ -630,8 +602,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         return 0;
     if (sched >= 64) {
         switch (sched) {
-            Y2P_ABL_CASE(6 + 64) Y2P_ABL_CASE(6 + 128) Y2P_ABL_CASE(6 + 256) Y2P_ABL_CASE(6 + 64 + 128) Y2P_ABL_CASE(6 + 128 + 256) Y2P_ABL_CASE(6 + 64 + 128 + 256)
-            Y2P_ABL_CASE(6 + 64 + 256)
+            Y2P_ABL_CASE(2 + 64) Y2P_ABL_CASE(2 + 128) Y2P_ABL_CASE(2 + 256) Y2P_ABL_CASE(2 + 64 + 128) Y2P_ABL_CASE(2 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 256)
             Y2P_ABL_CASE(2 + 64 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 1024) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512 + 1024)
             Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024)
             default: return 1;
@@ -639,7 +610,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
     }
 #undef Y2P_ABL_CASE
     switch (sched & 31) {
-        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(5) Y2P_CASE(6) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(13) Y2P_CASE(14) Y2P_CASE(18) Y2P_CASE(26)
+        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(18) Y2P_CASE(26)
         default: break;
     }
 #endif
