@@ -18,6 +18,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else ''
 
 
 GRAPH = os.environ.get('GRAPH', '1') != '0'
+if os.environ.get('PP_SCHED'):       # (A/B of a conv_pp.hip SCHED variant over the whole table)
+    ops.set_pp(dmapos=int(os.environ['PP_SCHED']))
 
 
 def timeit(fn, n=10):

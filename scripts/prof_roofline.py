@@ -3,7 +3,7 @@
     python scripts/prof_roofline.py <kernel-trace dir> <steps> [<FETCH_SIZE pmc dir> <WRITE_SIZE pmc dir>]
 
 Dominant kernel = the 3x3 implicit-GEMM forward / data-gradient launches with more than 64 filters (the set bench.py brackets with
-HIP events): conv3x3_tap_kernel<...> and conv_igemm_kernel<bf16, BN=128, .., KS=3, ..>.  Prints their launches per step, average
+HIP events): conv3x3_pp_kernel<...> (conv3x3_tap_kernel<...> in rounds 2-3) and conv_igemm_kernel<bf16, BN=128, .., KS=3, ..>.  Prints their launches per step, average
 duration (to be compared with roofline.avg_launch_ms) and, with the two PMC directories, the average HBM bytes per launch
 (FETCH_SIZE x 1024 x 2 on gfx950 + WRITE_SIZE x 1024: MI355X_MICROARCH.md "HBM"), which is roofline.traffic."""
 import os
@@ -15,7 +15,7 @@ from prof_summary import load          # noqa: E402
 
 
 def dominant(name):
-    if 'conv3x3_tap_kernel' in name:
+    if 'conv3x3_pp_kernel' in name or 'conv3x3_tap_kernel' in name:       # (round 4: ping-pong tap-fused kernel; rounds 2-3: conv3x3_tap_kernel)
         return True
     m = re.search(r'conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)      # T, BN, WGN, NSTAGE, KS
     if m:
@@ -36,7 +36,7 @@ def main():
           % (len(dom) / steps, tot / len(dom) / 1e3, tot / steps / 1e3, 100.0 * tot / sum(e - s for _, s, e in sel)))
     by = {}
     for n, d in dom:
-        k = 'conv3x3_tap_kernel' if 'conv3x3_tap' in n else re.sub(r'EEv.*', '', n.replace('_Z17', ''))[:70]
+        k = 'conv3x3_pp_kernel' if 'conv3x3_pp' in n else 'conv3x3_tap_kernel' if 'conv3x3_tap' in n else re.sub(r'EEv.*', '', n.replace('_Z17', ''))[:70]
         a = by.setdefault(k, [0, 0])
         a[0] += 1
         a[1] += d

@@ -208,9 +208,15 @@ TAP_VARIANTS = {'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1)}
 _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant and epilogue: minutes of CPU time when recomputed 12 times)
 
 
-@pytest.mark.parametrize('epilogue', ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn'])
-@pytest.mark.parametrize('variant', list(TAP_VARIANTS))
-@pytest.mark.parametrize('shape', TAP_SHAPES)
+TAP_EPILOGUES = ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn']
+# stream-K: every shape x every epilogue.  One workgroup per tile: the small shapes with every epilogue, and the bench shapes the launch rule
+# gives a tile grid (26x26 256->512 forward, 52x52 / 55x55 data gradients) -- the GPU box's host pays seconds per large case.
+TAP_CASES = [(s_, 'pp', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
+            [(s_, 'pp_tiles', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES[9:]] + \
+            [(s_, 'pp_tiles', e_) for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
+
+
+@pytest.mark.parametrize('shape,variant,epilogue', TAP_CASES, ids=['%s-%s-%s' % ('x'.join(map(str, c[0])), c[1], c[2]) for c in TAP_CASES])
 def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
     """The ping-pong tap-fused 3x3 kernel (conv_pp.hip: one halo image per 64-channel chunk, nine taps read from it), as stream-K and with
     one workgroup per tile, against the per-tap kernel on the same operands -- same products, a different f32 summation order across

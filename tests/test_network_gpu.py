@@ -746,6 +746,32 @@ def test_multi_scale_every_size_of_configs3(basedir):
         assert abs(res['bf16'][0] - res['f32'][0]) <= 3e-2 * abs(res['f32'][0]), (size, res['bf16'][0], res['f32'][0])
 
 
+def test_multi_scale_batch8_teacher_forced_forward(basedir):
+    """BASELINE configs[3] at ITS per-GPU batch (8 images): launch plans depend on M = B H W, so the five sizes the oracle tests only
+    touch at batch 2 (384 / 448 / 480 / 512 / 576) are run here at batch 8, bf16, in one multi-size session, and every layer of the training
+    forward is checked against the oracle on the engine's own stored inputs; the loss is finite, the padding lanes of the head stay zero."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B, classes = 8, 20
+    sizes = [384, 448, 480, 512, 576]
+    b, _ = make_builder('darknet', classes, 576, True, basedir)
+    sess = TrainSession(b, B, dtype='bf16', optimizer='adam', learning_rate=1e-4, seed=6, sizes=[(s_, s_) for s_ in sizes])
+    e = sess.engine
+    g = torch.Generator(device='cuda').manual_seed(12)
+    for size in sizes:
+        cells = size // 32
+        sess.set_size(size, size)
+        sess.upload_labels(data.synthetic_batch(B, classes, cells, cells, seed=size))
+        sess.forward_backward(torch.rand(B, size, size, 3, device='cuda', generator=g) * 255)
+        loss = sess.fetch()['total_loss']
+        assert np.isfinite(loss) and 0 < loss < 10, (size, loss)
+        out = e.output()
+        assert (out.h, out.w) == (cells, cells)
+        assert torch.all(e.act[out][0].float().reshape(-1, 128)[:B * cells * cells, 125:] == 0), size
+        worst = forward_teacher_forced(e, 'yolo2_darknet', strip(e.get_variables(), 'yolo2_darknet'), False)
+        print('\n%d batch 8 bf16 teacher-forced forward, worst rel-L2: %s' % (size, ['%s %.1e' % (n, r) for r, n in worst[:3]]))
+
+
 def test_tensorflow_checkpoint_and_event_file_round_trip(basedir, tmp_path):
     """a training session saved as a TensorFlow V2 checkpoint (the reference's tf.train.Saver layout: variables by TF
     scope name, global_step, <var>/Adam and <var>/Adam_1 slots) restores into a fresh session bit for bit, continues identically,

@@ -724,7 +724,7 @@ extern "C" int yolo2_debug_set_igemm_tap(int mode) {
 // ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
 // dmapos 0/1 = DMA pieces at the head of the LOAD phase / inside the MFMA phase; min_steps, min_share = the launch gates below (< 0: keep)
 static std::atomic<int> g_pp_grid{0};
-static std::atomic<int> g_pp_dmapos{2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
+static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_SCHED") ? atoi(getenv("YOLO2_PP_SCHED")) : 2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
 static std::atomic<long> g_pp_min_steps{18};
 static std::atomic<long> g_pp_min_share{24};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {

@@ -50,6 +50,13 @@ constexpr int y2p_leave(int order, int D, int tp, int hslots, bool skipidle) {
     } else { for (int k = 0; k <= D - 2; ++k) n += y2p_slot_loads(tp - k, hslots, skipidle); }                  // slots issued in LOAD(kt) .. LOAD(kt-D+2)
     return n;
 }
+// ORDER 7: what the SECOND group may leave in flight at the end of MFMA(tap tp) so that its pieces of step kt+2 have landed (the first group
+// reads that step's filter fragments before the second group's next LOAD-phase wait): the slots of LOAD(kt) .. LOAD(kt-D+3)
+constexpr int y2p_leave_m(int D, int tp, int hslots, bool skipidle) {
+    int n = 0;
+    for (int k = 0; k <= D - 3; ++k) n += y2p_slot_loads(tp - k, hslots, skipidle);
+    return n;
+}
 
 // HROWS = halo rows held (>= 256 + 2 W + 2, multiple of 8), NSB = filter ring depth (DMA runs NSB-1 steps ahead of the reads).
 // SCHED (A/B of where a step's three DMA pieces are issued; bits 0-2 = order):
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         park_pending = false;
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ORDER == 7 ? D - 2 : D - 1) * Y2P_LOADS) : "memory");      // zero KiBs, halo and filter tile kt_beg have landed (the newer slots stay in flight)
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
@@ -297,16 +304,18 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                         for (int i = 0; i < TM; ++i) fa[kk][i] = *(lds_frag_ptr)(uintptr_t)(aaddr[tp][i] ^ (unsigned)(kk * 32));
+                    if (ORDER != 7 || kt == kt_beg) {       // (order 7: only a segment's first step reads its filter fragments here)
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const unsigned bb = baddr[kk] + so;
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const unsigned bb = baddr[kk] + so;
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (ORDER == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (ORDER == 2 || ORDER == 3) { dma_halo(); dma_filter(); }
+                if (ORDER == 2 || ORDER == 3 || ORDER == 7) { dma_halo(); dma_filter(); }
                 if (ORDER == 4) dma_filter();
                 __builtin_amdgcn_sched_barrier(0);
                 // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
@@ -338,6 +347,22 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
                 if (PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (ORDER == 7) {
+                    // every MFMA of this step is issued: the filter fragments of step kt+1 go into the same registers now, their latency
+                    // under the last MFMAs, the barrier and the next LOAD phase's pixel reads
+                    if (!A_NOREAD && kt + 1 < kt_end) {
+                        const unsigned so1 = (unsigned)((stage_r == NSB - 1 ? 0 : stage_r + 1) * Y2P_BBYTES);
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const unsigned bb = baddr[kk] + so1;
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) fb[kk][j] = *(lds_frag_ptr)(uintptr_t)(bb + (unsigned)(j * 32 * ROWB));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!A_NODMA && wave >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(y2p_leave_m(D, tp, HSLOTS, SKIPIDLE)) : "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 ++kt;
@@ -615,7 +640,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
     }
 #endif
     switch (sched & 31) {
-        Y2P_CASE(2)
+        Y2P_CASE(2) Y2P_CASE(7)
         default: break;
     }
 #undef Y2P_CASE
