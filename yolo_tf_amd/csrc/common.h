@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/yolo2_hip.h"
 
 typedef __bf16 bf16;
@@ -94,6 +95,11 @@ __host__ __device__ static inline long y2_filter_koff(int tap, int c, int ld, in
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// The library's A/B switches are integers read once from the environment; unset = the measured default.
+static inline int y2_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 // 16-byte vector of T: 4 floats or 8 bf16
 template <typename T> struct Vec16;

@@ -576,12 +576,12 @@ struct Tune { int target_blocks; int wide; int remap; int stream; int cus; int s
 static const Tune &tune() {   // shape-selection constants (each the measured best: profiles/r01_igemm_*.txt, r03_igemm_variant_sweep.txt); two run-time switches remain
     static Tune t = [] {
         Tune v{352, 1, -1, 1, 256, 255, 1};   // K slicing only for grids below half the chip (see choose_ksplit)
-        if (const char *e = getenv("YOLO2_IGEMM_STREAM")) v.stream = atoi(e);       // 0: no stream-K anywhere (A/B, debugging a hand-off)
+        v.stream = y2_env_int("YOLO2_IGEMM_STREAM", v.stream);       // 0: no stream-K anywhere (A/B, debugging a hand-off)
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             v.cus = prop.multiProcessorCount;
-        if (const char *e = getenv("YOLO2_IGEMM_STREAM_WGS")) v.cus = atoi(e);      // workgroups of a stream-K launch (default: one per CU; yolo2_set_stream_workgroups at run time)
+        v.cus = y2_env_int("YOLO2_IGEMM_STREAM_WGS", v.cus);      // workgroups of a stream-K launch (default: one per CU; yolo2_set_stream_workgroups at run time)
         v.stream_max_tiles = 3 * v.cus;
         return v;
     }();
@@ -716,7 +716,7 @@ static constexpr bool igemm_wide_fits() {
 // tests can compare both variants on the same inputs
 // 0 = per-tap kernels only, non-zero = the ping-pong tap-fused kernel (conv_pp.hip) where its launch rule admits it (default).  (The round-2
 // tap-fused kernel it replaced -- slower on every layer it took, profiles/r04_pp2_sched_b16.txt column tap-r2 -- is gone.)
-static std::atomic<int> g_igemm_tap{getenv("YOLO2_IGEMM_TAP") ? atoi(getenv("YOLO2_IGEMM_TAP")) : 2};
+static std::atomic<int> g_igemm_tap{y2_env_int("YOLO2_IGEMM_TAP", 2)};
 extern "C" int yolo2_debug_set_igemm_tap(int mode) {
     g_igemm_tap.store(mode != 0 ? 2 : 0, std::memory_order_relaxed);
     return YOLO2_OK;
@@ -724,7 +724,7 @@ extern "C" int yolo2_debug_set_igemm_tap(int mode) {
 // ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
 // dmapos 0/1 = DMA pieces at the head of the LOAD phase / inside the MFMA phase; min_steps, min_share = the launch gates below (< 0: keep)
 static std::atomic<int> g_pp_grid{0};
-static std::atomic<int> g_pp_dmapos{getenv("YOLO2_PP_SCHED") ? atoi(getenv("YOLO2_PP_SCHED")) : 2};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
+static std::atomic<int> g_pp_dmapos{y2_env_int("YOLO2_PP_SCHED", 2)};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
 static std::atomic<long> g_pp_min_steps{18};
 static std::atomic<long> g_pp_min_share{24};
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
@@ -807,6 +807,10 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             else if (tiles_t * 10 >= (long)tu.cus * 6 && tiles_t <= tu.cus) grid = (int)tiles_t;
             else if (can_stream && ((units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus && tiles_t * 4 >= tu.cus) ||
                                     (bz.Y && M >= 8192 && units_p >= 10L * tu.cus))) grid = tu.cus;
+            // every workgroup of a stream-K launch must hold at least one K step: an owner waits for the flag of EVERY workgroup whose range
+            // lies inside its tile, and one without work never raises it (only a forced grid on a tiny problem gets here: the rule above
+            // asks for >= 10 steps per workgroup)
+            if (grid > units_p) grid = (int)units_p;
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
@@ -899,7 +903,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         return YOLO2_E_ARG;
     }
     int rc = 0;
-    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    static const bool first_direct = y2_env_int("YOLO2_FIRST_DIRECT", 1) != 0;
     if (first_direct && !bias && !bwd && act_alpha == 1.0f && y2_first_layer_shape(Cp, ldp, Nf, ldo, ksize)) {      // image layer: direct kernel (conv_first.hip)
         if (dtype != YOLO2_F32 && dtype != YOLO2_BF16) { yolo2_set_error("%s: bad dtype %d", fn, dtype); return YOLO2_E_ARG; }
         y2_first_layer_fwd(P, F, O, B, H, W, dtype, (hipStream_t)stream, bn_shift, bn_part);
@@ -910,7 +914,7 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     }
     bool stats_done = true;
     if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
-        static const bool fuse = !(getenv("YOLO2_FUSE_BN_BWD") && atoi(getenv("YOLO2_FUSE_BN_BWD")) == 0);
+        static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;
         const bool can = fuse && Nf % vec == 0;
         if (can) {
             Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,

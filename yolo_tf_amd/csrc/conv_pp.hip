@@ -63,6 +63,9 @@ constexpr int y2p_leave_m(int D, int tp, int hslots, bool skipidle) {
 //   0  DMA pieces, then the fragment reads                       1  all pieces behind the first four MFMAs of the MFMA phase
 //   2  fragment reads, then the pieces (issued under the reads' latency)      3  reads, lgkmcnt(0), then the pieces (read-free gap)
 //   4  reads + the two filter pieces in the LOAD phase, the halo piece behind the first four MFMAs
+//   7  as 2, with the FILTER fragments of step s+1 read behind the last MFMA of step s (into the registers those MFMAs just released; the
+//      second group then also waits, at the end of its MFMA phase, for its own DMA pieces of step s+2): 3-5 % slower than 2 on every 13x13 /
+//      26x26 layer (conv20 forward 150 vs 143 us on one box, profiles/r04_pp7_b16.txt) -- experiments build only
 //   (5 = as 2 with the pixel fragments of step s+1 read behind the MFMAs of step s, and 6 = no ping-pong at all, one barrier per step with
 //    every fragment read trailing the MFMAs that release its registers, were built and measured: conv20 forward 137 and 147 us against 129 for
 //    order 2 -- any read or DMA instruction inside a wave's MFMA stream delays its next MFMA -- profiles/r04_pp3_b16.txt, r04_pp5_b16.txt;
@@ -618,7 +621,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         if (W <= 27) { if (bwd) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(false, 312, 5, SCv); }             \
         else { if (bwd) Y2P_LAUNCH(true, 368, 4, SCv); else Y2P_LAUNCH(false, 368, 4, SCv); }                     \
         return 0;
-    if (W > 55) return 1;
+    if (W > 55 || (long)grid > (long)((M + Y2P_BM - 1) / Y2P_BM) * NT * (Cp / 64) * 9) return 1;      // (a workgroup without a K step would never raise its flag)
     const bool bwd = bz.Y != nullptr || (sched & 32) != 0;      // (+32, measurements only: the BN-backward instantiation without its sums)
 #ifdef Y2P_EXPERIMENTS      // (scripts/pp_experiments_build.sh: the SCHED variants and timing ablations behind profiles/r04_pp*.txt)
 #define Y2P_ABL_CASE(SCv)                                                                                          \
@@ -635,12 +638,12 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
     }
 #undef Y2P_ABL_CASE
     switch (sched & 31) {
-        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(18) Y2P_CASE(26)
+        Y2P_CASE(0) Y2P_CASE(1) Y2P_CASE(3) Y2P_CASE(4) Y2P_CASE(7) Y2P_CASE(10) Y2P_CASE(12) Y2P_CASE(18) Y2P_CASE(26)
         default: break;
     }
 #endif
     switch (sched & 31) {
-        Y2P_CASE(2) Y2P_CASE(7)
+        Y2P_CASE(2)
         default: break;
     }
 #undef Y2P_CASE

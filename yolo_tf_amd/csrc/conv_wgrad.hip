@@ -390,7 +390,7 @@ static WgradPlan wgrad_plan(int M, int Cin, int Cout, int ksize, int BC, int BNN
     const int CT = cdiv(Cin, BC), NT = cdiv(Cout, BNN);
     const int tgroups = (BC == 64 && wgrad_pairs_taps(Cin, ksize)) ? (ksize * ksize + 1) / 2 : ksize * ksize;
     p.tiles = tgroups * CT * NT;
-    static const int env_target = getenv("YOLO2_WGRAD_BLOCKS") ? atoi(getenv("YOLO2_WGRAD_BLOCKS")) : 0;
+    static const int env_target = y2_env_int("YOLO2_WGRAD_BLOCKS", 0);
     const int env_remap = -1;      // (XCD-local placement by rule below)
     // 128-wide tile (8 waves, two workgroups per CU): every block of the grid should be resident at once -- AT MOST 7/4 blocks per CU --
     // and keep >= 40 reduction tiles, else the 64 KB atomic epilogue and the ring prologue dominate.  26x26 256->512 (72 tiles),
@@ -472,7 +472,7 @@ static bool wgrad_small_tile(int Cin, int Cout, int ksize) {
 
 extern "C" int yolo2_conv2d_wgrad_accumulates(int B, int H, int W, int Cin, int ldx, int Cout, int ldy, int ksize, int dtype) {
     if (!(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0) || !(ksize == 1 || ksize == 3) || !(dtype == YOLO2_F32 || dtype == YOLO2_BF16)) return 1;
-    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    static const bool first_direct = y2_env_int("YOLO2_FIRST_DIRECT", 1) != 0;
     if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize)) return 1;      // cross-workgroup atomics
     if (g_wgrad_variant != 0) return 1;
     const int bkp = dtype == YOLO2_BF16 ? 32 : 16;
@@ -493,7 +493,7 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
     // 32-bit byte offsets below 2^31 on both operands (DMA descriptors)
     Y2_CHECK_ARG((size_t)B * H * W * (size_t)(ldx > ldy ? ldx : ldy) * esz < (1ull << 31));
     hipStream_t st = (hipStream_t)stream;
-    static const bool first_direct = !(getenv("YOLO2_FIRST_DIRECT") && atoi(getenv("YOLO2_FIRST_DIRECT")) == 0);
+    static const bool first_direct = y2_env_int("YOLO2_FIRST_DIRECT", 1) != 0;
     if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize) && (dtype == YOLO2_F32 || dtype == YOLO2_BF16)) {
         y2_first_layer_wgrad(X, dY, dW, B, H, W, Cin, dtype, st);                       // image layer: direct kernel (conv_first.hip)
         for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = -1;

@@ -64,7 +64,7 @@ def staggered(n, dtype, device, fill=0.0):
     process.  The caching allocator hands out 2 MiB-aligned blocks, so equally sized arenas that one kernel walks in lock step (Adam reads
     element i of four of them at once; a filter gradient reads pixel m of x and dY) otherwise sit at identical offsets of the HBM
     channel interleave: measured 418 us for the Adam pass with 2 MiB-aligned arenas against 377 us with 4 KiB of stagger; whole step +0.5..0.8 % with 4-68 KiB, best at 20
-    (scripts/arena_alias_bench.py, profiles/r03_arena_stagger.txt).  YOLO2_ALLOC_SKEW_KB=0 switches it off (A/B)."""
+    (scripts/arena_alias_bench.py, profiles/r03_arena_stagger.txt)."""
     esz = torch.empty(0, dtype=dtype).element_size()
     if _SKEW_KB <= 0 or n * esz < (1 << 20):
         return torch.full((n,), fill, dtype=dtype, device=device) if fill else torch.zeros(n, dtype=dtype, device=device)
@@ -296,7 +296,7 @@ class Engine(object):
                     need = B * (x.h // 2) * (x.w // 2) * x.c
                     if self.training and ('pool_idx' not in st or st['pool_idx'].numel() < need):
                         st['pool_idx'] = torch.zeros(need, dtype=torch.uint8, device=dev)
-                    # the raw output AT the arg-max, a quarter of y: all the layer's backward reduction needs (YOLO2_POOL_YMAX=0: A/B)
+                    # the raw output AT the arg-max, a quarter of y: all the layer's backward reduction needs
                     if self.training and self.pool_ymax and ('pool_ymax' not in st or st['pool_ymax'].numel() < need):
                         st['pool_ymax'] = staggered(need, T, dev)
             # forward only: the pool of an activation that has OTHER readers too (Darknet-19's 26x26 passthrough) still comes out of the BN
