@@ -415,12 +415,15 @@ int yolo2_selftest_tr16(short *out, void *stream);
 int yolo2_debug_last_conv_plan(int *out8);
 /* measurement hook: launches an empty kernel (bench.py calibrates the overhead of its HIP-event brackets with it) */
 int yolo2_debug_noop(void *stream);
-/* test hook: which tap-fused 3x3 implicit-GEMM variant the calling process uses: 0 = none (per-tap kernels), 1 = the round-2
- * tap-fused kernel, 2 = the ping-pong tap-fused kernel (default) */
+/* test hook (process-wide): 0 = per-tap 3x3 kernels only; non-zero = the ping-pong tap-fused kernel (csrc/conv_pp.hip) wherever its
+ * launch rule admits it (default) */
 int yolo2_debug_set_igemm_tap(int mode);
-/* test / A-B hook for the ping-pong kernel: grid 0 = by rule, 1 = stream-K, 2 = one workgroup per tile; dmapos 0/1; launch gates
- * (K steps per tile, K steps per workgroup); a negative argument keeps the current value */
-int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share);
+/* test / A-B hook for the ping-pong kernel.  grid: 0 = by rule (default), 1 = stream-K over one workgroup per CU, 2 = one workgroup per
+ * tile, >= 8 = that many workgroups, <= -2 = every tile cut into exactly -grid shares, -1 = keep; a stream-K grid never exceeds the
+ * number of K steps.  sched: the kernel's LOAD-phase order (2 in the product build; others only in scripts/pp_experiments_build.sh's;
+ * an order the library was not built with sends the layer to the per-tap kernels).  min_steps / min_share: the rule's gates (K steps
+ * per tile, K steps per workgroup).  A negative argument keeps the current value. */
+int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
 int yolo2_debug_last_wgrad_plan(int *out8);
 /* 0 = transpose-read fragment gather (product), 1 = scalar reference gather (layout-proof, slow); process-wide, tests only */
 void yolo2_debug_set_wgrad_variant(int variant);

@@ -209,11 +209,15 @@ _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant
 
 TAP_EPILOGUES = ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn']
 # stream-K: every shape x every epilogue.  One workgroup per tile: the bench shapes the launch rule gives a tile grid (26x26 256->512 forward,
-# 52x52 / 55x55 data gradients).  (Shapes with fewer K steps than CUs are not in this list yet: a forced stream-K grid used to leave
-# workgroups without work whose flags an owner then waited for -- the launch now clamps the grid to the number of K steps, conv_igemm.hip --
-# and that case has not had a run on hardware.)
+# 52x52 / 55x55 data gradients).
 TAP_CASES = [(s_, 'pp', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
             [(s_, 'pp_tiles', e_) for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
+# Shapes with fewer K steps than CUs (odd sizes, partial tiles, 3 and 5 chunks, H != W).  A forced stream-K grid used to leave workgroups without
+# work whose flags an owner then waited for (a hang, found by these shapes); launch_conv now clamps the grid to the number of K steps.  The
+# fix was made after the round's last GPU-minute, so the shapes join the default list only once scripts/gpu_round5_first.sh has seen them green.
+if os.environ.get('YOLO2_TEST_TINY_TAP_SHAPES'):
+    _tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
+    TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles') for s_ in _tiny]
 
 
 @pytest.mark.parametrize('shape,variant,epilogue', TAP_CASES, ids=['%s-%s-%s' % ('x'.join(map(str, c[0])), c[1], c[2]) for c in TAP_CASES])

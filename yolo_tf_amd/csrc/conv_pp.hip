@@ -85,7 +85,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     constexpr bool SKIPIDLE = (SCHED & 8) != 0, PRIO = (SCHED & 16) != 0;
     // timing ablations (wrong results by design; scripts/pp_sweep.py): +64 no MFMAs, +128 no fragment reads, +256 no DMA inside the K loop
     constexpr bool A_NOMFMA = (SCHED & 64) != 0, A_NOREAD = (SCHED & 128) != 0, A_NODMA = (SCHED & 256) != 0;
-    constexpr bool A_NOEPI = (SCHED & 512) != 0, A_NOHANDOFF = (SCHED & 1024) != 0;      // +512 no epilogue (stores, statistics), +1024 no stream-K hand-off traffic
+    constexpr bool A_NOEPI = (SCHED & 512) != 0, A_NOHANDOFF = (SCHED & 1024) != 0;
+    // +4096 (with +512): s_memtime stamps at the phase boundaries of every K step; each wave leaves its sums in O as eight 64-bit words
+    // {kernel cycles, LOAD issue, LOAD wait, barrier after LOAD, MFMA issue, barrier after MFMA, steps, workgroup * 8 + wave}
+    // (scripts/pp_phase_cycles.py: cycles per phase, and the shader clock = kernel cycles / kernel duration)
+    constexpr bool A_TIME = (SCHED & 4096) != 0;
+    static_assert(!A_TIME || A_NOEPI, "the cycle stamps go where the output tile would");      // +512 no epilogue (stores, statistics), +1024 no stream-K hand-off traffic
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
     // (ORDER 4 issues the halo piece half a step later: one slot less)
     static_assert(HROWS % 8 == 0 && HSLOTS <= TAPS + (ORDER == 4 ? 0 : 1) - D && D >= 2 && RING + NSB * Y2P_BBYTES <= 160 * 1024, "LDS plan");
@@ -116,6 +121,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
 
   bool park_pending = false;
+  unsigned long long tm_k0 = 0, tm_issue = 0, tm_wait = 0, tm_barl = 0, tm_mfma = 0, tm_barm = 0, tm_steps = 0;
+  if (A_TIME) tm_k0 = __builtin_amdgcn_s_memtime();
   for (bool first_seg = true;; first_seg = false) {
     if (su >= su_end) break;
     const int t = (int)(su / nk);
@@ -281,6 +288,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { fa[kk][i][e] = (bf16)(float)(lane_s + e); fb[kk][i][e] = (bf16)(float)(lane_s - e); }
     }
+    unsigned long long tm_pa = 0, tm_p1 = 0, tm_p2 = 0, tm_p3 = 0;      // (A_TIME) stamps of the previous step, consumed behind the next lgkmcnt(0)
+    bool tm_prev = false;
     int kt = kt_beg;                                     // the K step the next executed phase pair belongs to
     int stage_r = 0, stage_i = D;                        // ring stage read by step kt / filled by the DMA slot of step kt (= stage of step kt + D)
 
@@ -300,6 +309,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 // DMA instructions this wave may leave in flight at the end of LOAD(tp): everything issued after its pieces of step kt+1
                 constexpr int LEAVE = y2p_leave(ORDER, D, tp, HSLOTS, SKIPIDLE);
                 // ---- LOAD phase
+                unsigned long long tm_0 = 0, tm_a = 0, tm_1 = 0, tm_2 = 0, tm_3 = 0;
+                if (A_TIME) { tm_0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
                 if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
                 if (!A_NOREAD) {
@@ -321,12 +332,21 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 if (ORDER == 2 || ORDER == 3 || ORDER == 7) { dma_halo(); dma_filter(); }
                 if (ORDER == 4) dma_filter();
                 __builtin_amdgcn_sched_barrier(0);
+                if (A_TIME) { tm_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
                 // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
                 if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
                 // lgkmcnt(0) through the builtin, not asm: hipcc's own wait insertion must KNOW that every fragment read has returned here, or
                 // it counts the LOAD-phase reads as still outstanding and puts lgkmcnt(3) / lgkmcnt(1) in front of the later MFMA groups --
                 // which then wait for the ORDER-5 prefetch reads issued a few instructions earlier (gfx9 encoding: vmcnt 63, expcnt 7, lgkmcnt 0)
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (A_TIME) {       // every stamp issued so far has returned (the wait above counts scalar memory too)
+                    if (tm_prev) { tm_wait += tm_p1 - tm_pa; tm_barl += tm_p2 - tm_p1; tm_mfma += tm_p3 - tm_p2; tm_barm += tm_0 - tm_p3; }
+                    tm_issue += tm_a - tm_0;
+                    ++tm_steps;
+                    __builtin_amdgcn_sched_barrier(0);
+                    tm_1 = __builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (A_NOMFMA && !A_NOREAD) {        // (ablation: the fragments count as used)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(fa[kk][0]), "v"(fa[kk][1]), "v"(fb[kk][0]), "v"(fb[kk][1]));
@@ -334,6 +354,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- MFMA phase: registers only
+                if (A_TIME) { tm_2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
                 if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -350,6 +371,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
                 if (PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                if (A_TIME) {
+                    tm_3 = __builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_sched_barrier(0);
+                    tm_pa = tm_a; tm_p1 = tm_1; tm_p2 = tm_2; tm_p3 = tm_3; tm_prev = true;
+                }
                 if (ORDER == 7) {
                     // every MFMA of this step is issued: the filter fragments of step kt+1 go into the same registers now, their latency
                     // under the last MFMAs, the barrier and the next LOAD phase's pixel reads
@@ -606,6 +632,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (A_TIME && lane == 0) {
+      unsigned long long *dbg = reinterpret_cast<unsigned long long *>(O) + ((size_t)wx * NW + wave) * 8;
+      dbg[0] = __builtin_amdgcn_s_memtime() - tm_k0; dbg[1] = tm_issue; dbg[2] = tm_wait; dbg[3] = tm_barl;
+      dbg[4] = tm_mfma; dbg[5] = tm_barm; dbg[6] = tm_steps; dbg[7] = (unsigned long long)(wx * NW + wave);
+  }
 }
 
 // Launch (called by conv_igemm.hip launch_conv once it has decided that the shape takes this kernel): `grid` workgroups share the
@@ -632,7 +663,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         switch (sched) {
             Y2P_ABL_CASE(2 + 64) Y2P_ABL_CASE(2 + 128) Y2P_ABL_CASE(2 + 256) Y2P_ABL_CASE(2 + 64 + 128) Y2P_ABL_CASE(2 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 256)
             Y2P_ABL_CASE(2 + 64 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 1024) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512 + 1024)
-            Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024)
+            Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024) Y2P_ABL_CASE(2 + 512 + 4096)
             default: return 1;
         }
     }

@@ -337,7 +337,7 @@ def noop():
 
 
 def set_igemm_tap(mode):
-    """Test hook: tap-fused 3x3 implicit-GEMM variant (process-wide): 0 none, 1 round-2 tap-fused kernel, 2 ping-pong kernel (default)."""
+    """Test hook (process-wide): 0 = per-tap 3x3 kernels only, non-zero = the ping-pong tap-fused kernel where its launch rule admits it (default)."""
     _lib.load().yolo2_debug_set_igemm_tap(int(mode))
 
 
