@@ -121,8 +121,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
 
   bool park_pending = false;
+#ifdef Y2P_EXPERIMENTS
   unsigned long long tm_k0 = 0, tm_issue = 0, tm_wait = 0, tm_barl = 0, tm_mfma = 0, tm_barm = 0, tm_steps = 0;
   if (A_TIME) tm_k0 = __builtin_amdgcn_s_memtime();
+#endif
   for (bool first_seg = true;; first_seg = false) {
     if (su >= su_end) break;
     const int t = (int)(su / nk);
@@ -288,8 +290,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { fa[kk][i][e] = (bf16)(float)(lane_s + e); fb[kk][i][e] = (bf16)(float)(lane_s - e); }
     }
+#ifdef Y2P_EXPERIMENTS
     unsigned long long tm_pa = 0, tm_p1 = 0, tm_p2 = 0, tm_p3 = 0;      // (A_TIME) stamps of the previous step, consumed behind the next lgkmcnt(0)
     bool tm_prev = false;
+#endif
     int kt = kt_beg;                                     // the K step the next executed phase pair belongs to
     int stage_r = 0, stage_i = D;                        // ring stage read by step kt / filled by the DMA slot of step kt (= stage of step kt + D)
 
@@ -309,8 +313,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 // DMA instructions this wave may leave in flight at the end of LOAD(tp): everything issued after its pieces of step kt+1
                 constexpr int LEAVE = y2p_leave(ORDER, D, tp, HSLOTS, SKIPIDLE);
                 // ---- LOAD phase
+#ifdef Y2P_EXPERIMENTS
                 unsigned long long tm_0 = 0, tm_a = 0, tm_1 = 0, tm_2 = 0, tm_3 = 0;
                 if (A_TIME) { tm_0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 if (ORDER == 0) { dma_halo(); dma_filter(); }
                 const unsigned so = (unsigned)(stage_r * Y2P_BBYTES);
                 if (!A_NOREAD) {
@@ -332,13 +338,16 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 if (ORDER == 2 || ORDER == 3 || ORDER == 7) { dma_halo(); dma_filter(); }
                 if (ORDER == 4) dma_filter();
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef Y2P_EXPERIMENTS
                 if (A_TIME) { tm_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 // this wave's pieces of step kt+1 have landed (the newest LEAVE instructions stay in flight)
                 if (!A_NODMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LEAVE) : "memory");
                 // lgkmcnt(0) through the builtin, not asm: hipcc's own wait insertion must KNOW that every fragment read has returned here, or
                 // it counts the LOAD-phase reads as still outstanding and puts lgkmcnt(3) / lgkmcnt(1) in front of the later MFMA groups --
                 // which then wait for the ORDER-5 prefetch reads issued a few instructions earlier (gfx9 encoding: vmcnt 63, expcnt 7, lgkmcnt 0)
                 __builtin_amdgcn_s_waitcnt(0xc07f);
+#ifdef Y2P_EXPERIMENTS
                 if (A_TIME) {       // every stamp issued so far has returned (the wait above counts scalar memory too)
                     if (tm_prev) { tm_wait += tm_p1 - tm_pa; tm_barl += tm_p2 - tm_p1; tm_mfma += tm_p3 - tm_p2; tm_barm += tm_0 - tm_p3; }
                     tm_issue += tm_a - tm_0;
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                     tm_1 = __builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_sched_barrier(0);
                 }
+#endif
                 if (A_NOMFMA && !A_NOREAD) {        // (ablation: the fragments count as used)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) asm volatile("" ::"v"(fa[kk][0]), "v"(fa[kk][1]), "v"(fb[kk][0]), "v"(fb[kk][1]));
@@ -354,7 +364,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- MFMA phase: registers only
+#ifdef Y2P_EXPERIMENTS
                 if (A_TIME) { tm_2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#endif
                 if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
@@ -371,11 +383,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
                 if (PRIO) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef Y2P_EXPERIMENTS
                 if (A_TIME) {
                     tm_3 = __builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_sched_barrier(0);
                     tm_pa = tm_a; tm_p1 = tm_1; tm_p2 = tm_2; tm_p3 = tm_3; tm_prev = true;
                 }
+#endif
                 if (ORDER == 7) {
                     // every MFMA of this step is issued: the filter fragments of step kt+1 go into the same registers now, their latency
                     // under the last MFMAs, the barrier and the next LOAD phase's pixel reads
@@ -632,11 +646,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+#ifdef Y2P_EXPERIMENTS
   if (A_TIME && lane == 0) {
       unsigned long long *dbg = reinterpret_cast<unsigned long long *>(O) + ((size_t)wx * NW + wave) * 8;
       dbg[0] = __builtin_amdgcn_s_memtime() - tm_k0; dbg[1] = tm_issue; dbg[2] = tm_wait; dbg[3] = tm_barl;
       dbg[4] = tm_mfma; dbg[5] = tm_barm; dbg[6] = tm_steps; dbg[7] = (unsigned long long)(wx * NW + wave);
   }
+#endif
 }
 
 // Launch (called by conv_igemm.hip launch_conv once it has decided that the shape takes this kernel): `grid` workgroups share the
