@@ -2,7 +2,8 @@
 # round 4, run 5: ORDER 6 (single-phase software pipeline), fixed-cost breakdown of the ping-pong kernel, atomic-add rate, measured pin errors
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 make -C oracle >/dev/null 2>&1
-bash scripts/pp_experiments_build.sh || exit 1
+# (at the time this ran, pp_experiments_build.sh rebuilt libyolo2hip.so in place; it now builds libyolo2hip_exp.so, selected with YOLO2_LIB_PATH)
+bash scripts/pp_experiments_build.sh || exit 1; export YOLO2_LIB_PATH=$PWD/yolo_tf_amd/csrc/libyolo2hip_exp.so
 C="per-tap:0:0:0,s2:2:1:2,s6:2:1:6,s14:2:1:14,s2tile:2:2:2,s6tile:2:2:6"
 B=16 CONFIGS=$C timeout 600 python scripts/pp_sweep.py > gpurun_out/pp5_b16.log 2>&1; cat gpurun_out/pp5_b16.log
 B=8 CONFIGS=$C timeout 600 python scripts/pp_sweep.py > gpurun_out/pp5_b8.log 2>&1; cat gpurun_out/pp5_b8.log

@@ -8,10 +8,12 @@ make -C oracle >/dev/null 2>&1
 { hostname; /opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; } > gpurun_out/r5_box.txt 2>&1
 YOLO2_TEST_TINY_TAP_SHAPES=1 timeout 240 python -m pytest tests/test_kernels_gpu.py -k "tap_fused and (3x5x7 or 2x19x19 or 1x27x28 or 5x10x10)" -q -p no:cacheprovider -x -o faulthandler_timeout=20 --durations=5 2>&1 | tail -25 > gpurun_out/r5_tiny_tap.log; tail -8 gpurun_out/r5_tiny_tap.log
 timeout 200 python -m pytest tests/test_kernels_gpu.py -k "nms" -q -p no:cacheprovider --durations=5 2>&1 | tail -12 > gpurun_out/r5_nms.log; tail -4 gpurun_out/r5_nms.log
-cp yolo_tf_amd/csrc/libyolo2hip.so /tmp/libyolo2hip_product.so
-bash scripts/pp_experiments_build.sh > gpurun_out/r5_expbuild.log 2>&1 && {
-  timeout 300 python scripts/pp_phase_cycles.py > gpurun_out/r5_phase_cycles.log 2>&1; cat gpurun_out/r5_phase_cycles.log
-  GRID=2 LAYERS=conv8,conv5 timeout 200 python scripts/pp_phase_cycles.py > gpurun_out/r5_phase_cycles_tiles.log 2>&1; cat gpurun_out/r5_phase_cycles_tiles.log
-}
-cp /tmp/libyolo2hip_product.so yolo_tf_amd/csrc/libyolo2hip.so
+# (build yolo_tf_amd/csrc/libyolo2hip_exp.so with scripts/pp_experiments_build.sh BEFORE the call: minutes of host time, and the .so travels)
+EXP=$R/yolo_tf_amd/csrc/libyolo2hip_exp.so
+if [ -f $EXP ]; then
+  YOLO2_LIB_PATH=$EXP timeout 300 python scripts/pp_phase_cycles.py > gpurun_out/r5_phase_cycles.log 2>&1; cat gpurun_out/r5_phase_cycles.log
+  YOLO2_LIB_PATH=$EXP GRID=2 LAYERS=conv8,conv5 timeout 200 python scripts/pp_phase_cycles.py > gpurun_out/r5_phase_cycles_tiles.log 2>&1; cat gpurun_out/r5_phase_cycles_tiles.log
+else
+  echo "no experiments library: run scripts/pp_experiments_build.sh first" | tee gpurun_out/r5_phase_cycles.log
+fi
 timeout 900 python -m pytest tests/test_bench_shapes_gpu.py -q -p no:cacheprovider --durations=8 2>&1 | tail -14 > gpurun_out/r5_bench_shapes.log; tail -3 gpurun_out/r5_bench_shapes.log
