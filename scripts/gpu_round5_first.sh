@@ -2,7 +2,8 @@
 # First GPU call of the next round (everything here was written after round 4's GPU budget was spent; each step is bounded by its own timeout):
 #  1. the tiny tap-fused shapes that hung before the stream-K grid clamp (tests/test_kernels_gpu.py, YOLO2_TEST_TINY_TAP_SHAPES), NMS at N = 4096 / 4001
 #  2. in-kernel cycle stamps of the ping-pong kernel: cycles per phase and the shader clock a launch really gets (scripts/pp_phase_cycles.py)
-#  3. durations of the slowest GPU test files, so that the suite's total can be budgeted
+#  3. the four-rows-in-flight BN consumers: gated tests, then the A/B per layer shape (scripts/bn_rows_in_flight.py)
+#  4. durations of the slowest GPU test files, so that the suite's total can be budgeted
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 make -C oracle >/dev/null 2>&1
 { hostname; /opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; } > gpurun_out/r5_box.txt 2>&1
@@ -16,4 +17,6 @@ if [ -f $EXP ]; then
 else
   echo "no experiments library: run scripts/pp_experiments_build.sh first" | tee gpurun_out/r5_phase_cycles.log
 fi
+YOLO2_TEST_BN_ROWS4=1 timeout 200 python -m pytest tests/test_kernels_gpu.py -k "bn_consumers or rows_in_flight" -q -p no:cacheprovider -x 2>&1 | tail -6 > gpurun_out/r5_bn_rows4_tests.log; tail -3 gpurun_out/r5_bn_rows4_tests.log
+timeout 200 python scripts/bn_rows_in_flight.py > gpurun_out/r5_bn_rows_in_flight.log 2>&1; cat gpurun_out/r5_bn_rows_in_flight.log
 timeout 900 python -m pytest tests/test_bench_shapes_gpu.py -q -p no:cacheprovider --durations=8 2>&1 | tail -14 > gpurun_out/r5_bench_shapes.log; tail -3 gpurun_out/r5_bench_shapes.log
