@@ -8,16 +8,19 @@ over N GPUs of one node (one process per GPU, RCCL gradient all-reduce overlappe
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --gpus 8 --global-batch 64 --names 80     (BASELINE configs[2]: strong scaling, 8 images per GPU)
+    python bench.py --gpus 8 --shard-optimizer                 (reduce-scatter / 1/N update / all-gather instead of all-reduce + replicated update)
+    python bench.py --multiscale [--gpus 4]                    (BASELINE configs[3]: a different input size every step)
 
 A "step" = per-image standardisation -> forward (batch-stat BN) -> YOLOv2 loss fwd+bwd -> backward
 -> gradient all-reduce (N>1) -> Adam, on a synthetic batch that is already resident in HBM.
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline      the dominant kernel (conv_igemm_kernel<bf16,128,2>: 3x3/1x1 forward + data-gradient
-                convolutions with > 64 filters) -- algorithmic FLOPs / HIP-event time of its
-                launches inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak
-  cpu_baseline  the NumPy oracle's training step (oracle/yolo2_ref.py, a port: TF-1.0 cannot run
-                here) on one 416x416 image on the host cores (rank 0, N=1 only), plus SURVEY 8(d)'s other legs: the
-                torch-CPU (oneDNN) conv stack at batch 8 and the single-thread C restatement of the reference NMS
+  roofline      the dominant kernel: the 24 3x3 forward + data-gradient launches with > 64 filters (conv3x3_pp_kernel on images up to
+                55 wide, conv_igemm_kernel<bf16,128,...,KS=3> on the 104x104 stage) -- algorithmic FLOPs / RAW HIP-event time of
+                those launches in instrumented steps right after the timed region, against the 2.5 PFLOP/s dense bf16 MFMA
+                peak; the bracket-calibrated figures and the PMC traffic constant (profiles/dominant_kernel_pmc.json) ride along
+  cpu_baseline  value = the torch-CPU (oneDNN) forward+backward of the same conv stack at batch 8 on the host cores (rank 0, N=1
+                only; oracle/torch_cpu_ref.py, a port: TF-1.0 cannot run here); sub-fields: the NumPy oracle's full training
+                step on one image (oracle/yolo2_ref.py) and the single-thread C restatement of the reference NMS
   detect        BASELINE configs[4]: batch-256 detect p50/p99 with (a) the network's own scores, (b) the sparse and
                 (c) the dense NMS stress inputs of BASELINE.md section 2 written over the decoded boxes
 """
