@@ -3,7 +3,8 @@
 #  1. the tiny tap-fused shapes that hung before the stream-K grid clamp (tests/test_kernels_gpu.py, YOLO2_TEST_TINY_TAP_SHAPES), NMS at N = 4096 / 4001
 #  2. in-kernel cycle stamps of the ping-pong kernel: cycles per phase and the shader clock a launch really gets (scripts/pp_phase_cycles.py)
 #  3. the four-rows-in-flight BN consumers: gated tests, then the A/B per layer shape (scripts/bn_rows_in_flight.py)
-#  4. durations of the slowest GPU test files, so that the suite's total can be budgeted
+#  4. the long-share launch-rule clause at batch 8 (YOLO2_PP_LONG_SHARE=26)
+#  5. durations of the slowest GPU test files, so that the suite's total can be budgeted
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 make -C oracle >/dev/null 2>&1
 { hostname; /opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; } > gpurun_out/r5_box.txt 2>&1
@@ -19,4 +20,14 @@ else
 fi
 YOLO2_TEST_BN_ROWS4=1 timeout 200 python -m pytest tests/test_kernels_gpu.py -k "bn_consumers or rows_in_flight" -q -p no:cacheprovider -x 2>&1 | tail -6 > gpurun_out/r5_bn_rows4_tests.log; tail -3 gpurun_out/r5_bn_rows4_tests.log
 timeout 200 python scripts/bn_rows_in_flight.py > gpurun_out/r5_bn_rows_in_flight.log 2>&1; cat gpurun_out/r5_bn_rows_in_flight.log
+# batch-8 launch-rule candidate: COCO-80 batch 8 step with and without the long-share clause, same box, twice each
+for i in 1 2; do
+  for v in 0 26; do
+    YOLO2_PP_LONG_SHARE=$v python bench.py --batch 8 --names 80 --steps 60 --warmup 10 --no-cpu-baseline --no-detect --no-kernel-timer 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); print('long_share $v run $i: %.3f ms/step %.0f img/s' % (j['ms_per_step'], j['value']))" | tee -a gpurun_out/r5_long_share_b8.log
+  done
+done
 timeout 900 python -m pytest tests/test_bench_shapes_gpu.py -q -p no:cacheprovider --durations=8 2>&1 | tail -14 > gpurun_out/r5_bench_shapes.log; tail -3 gpurun_out/r5_bench_shapes.log
