@@ -145,3 +145,53 @@ def test_checkpoint_restore_remaps_optimizer_slots_when_only_the_arena_offsets_m
     other.optimizer.slots[0][:] = 1.0
     checkpoint.restore(path, other)
     assert float(other.optimizer.slots[0].sum()) == 80.0   # untouched: layouts name different variables
+
+
+def _streamk_segments(tiles, nk, G):
+    """The flat (tile, K step) partition of conv_pp.hip / conv_igemm.hip's stream-K launches, restated: workgroup w takes
+    [w S / G, (w + 1) S / G) of S = tiles * nk steps and walks it tile by tile -> per workgroup a list of (tile, kt_beg, kt_end)."""
+    S = tiles * nk
+    out = []
+    for w in range(G):
+        su, end, segs = w * S // G, (w + 1) * S // G, []
+        while su < end:
+            t = su // nk
+            kb = su - t * nk
+            ke = min(nk, kb + (end - su))
+            segs.append((t, kb, ke))
+            su += ke - kb
+        out.append(segs)
+    return out
+
+
+@pytest.mark.parametrize('tiles,nk,G', [(88, 432, 256), (88, 144, 256), (44, 144, 256), (264, 144, 256), (172, 36, 256), (88, 72, 224), (48, 432, 256),
+                                        (24, 144, 256), (1, 9, 9), (2, 18, 36), (5, 45, 225)])
+def test_stream_k_partition_invariants_the_hand_off_relies_on(tiles, nk, G):
+    """What the stream-K hand-off assumes of the partition: every K step belongs to exactly one workgroup; a tail (a segment
+    that does not start its tile) is always the FIRST segment of its workgroup, so it is parked before the workgroup can wait for anything;
+    the owner of a tile (holder of K step 0) has the lowest index of the tile's workgroups and its partners are the workgroups right after it;
+    and -- the case a forced grid on a tiny problem violated, which hung an owner on a flag nobody raises -- no workgroup is empty as long as
+    the launch has at most as many workgroups as K steps (launch_conv clamps the grid to that)."""
+    assert G <= tiles * nk
+    segs = _streamk_segments(tiles, nk, G)
+    cover = np.zeros((tiles, nk), np.int32)
+    holders = [[] for _ in range(tiles)]
+    for w, ss in enumerate(segs):
+        assert ss, 'workgroup %d has no K step' % w
+        for i, (t, kb, ke) in enumerate(ss):
+            cover[t, kb:ke] += 1
+            holders[t].append((kb, w))
+            if kb > 0:
+                assert i == 0, 'a tail segment must be the first segment of its workgroup'
+    assert np.all(cover == 1)
+    for t in range(tiles):
+        hs = sorted(holders[t])
+        ws = [w for _, w in hs]
+        assert hs[0][0] == 0 and ws == list(range(ws[0], ws[0] + len(ws))), 'owner first, partners consecutive'
+
+
+def test_stream_k_grid_larger_than_the_k_steps_leaves_workgroups_empty():
+    """Why launch_conv clamps: 9 K steps over 256 workgroups -- the owner of the only tile (workgroup 28) would wait for workgroup 29's flag,
+    and workgroup 29 has nothing to park."""
+    segs = _streamk_segments(1, 9, 256)
+    assert [w for w, s in enumerate(segs) if s][:2] == [28, 56] and not segs[29]
