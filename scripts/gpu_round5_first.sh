@@ -1,15 +1,13 @@
 #!/bin/bash
 # First GPU call of the next round (everything here was written after round 4's GPU budget was spent; each step is bounded by its own timeout):
-#  1. the tiny tap-fused shapes that hung before the stream-K grid clamp (tests/test_kernels_gpu.py, YOLO2_TEST_TINY_TAP_SHAPES), NMS at N = 4096 / 4001
+#  1. the tiny tap-fused shapes that hung before the stream-K grid clamp (tests/test_kernels_gpu.py, YOLO2_TEST_TINY_TAP_SHAPES)
 #  2. in-kernel cycle stamps of the ping-pong kernel: cycles per phase and the shader clock a launch really gets (scripts/pp_phase_cycles.py)
 #  3. the four-rows-in-flight BN consumers: gated tests, then the A/B per layer shape (scripts/bn_rows_in_flight.py)
 #  4. the long-share launch-rule clause at batch 8 (YOLO2_PP_LONG_SHARE=26)
-#  5. durations of the slowest GPU test files, so that the suite's total can be budgeted
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 make -C oracle >/dev/null 2>&1
 { hostname; /opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; } > gpurun_out/r5_box.txt 2>&1
 YOLO2_TEST_TINY_TAP_SHAPES=1 timeout 240 python -m pytest tests/test_kernels_gpu.py -k "tap_fused and (3x5x7 or 2x19x19 or 1x27x28 or 5x10x10)" -q -p no:cacheprovider -x -o faulthandler_timeout=20 --durations=5 2>&1 | tail -25 > gpurun_out/r5_tiny_tap.log; tail -8 gpurun_out/r5_tiny_tap.log
-timeout 200 python -m pytest tests/test_kernels_gpu.py -k "nms" -q -p no:cacheprovider --durations=5 2>&1 | tail -12 > gpurun_out/r5_nms.log; tail -4 gpurun_out/r5_nms.log
 # (build yolo_tf_amd/csrc/libyolo2hip_exp.so with scripts/pp_experiments_build.sh BEFORE the call: minutes of host time, and the .so travels)
 EXP=$R/yolo_tf_amd/csrc/libyolo2hip_exp.so
 if [ -f $EXP ]; then
@@ -30,4 +28,3 @@ for l in sys.stdin:
         j=json.loads(l); print('long_share $v run $i: %.3f ms/step %.0f img/s' % (j['ms_per_step'], j['value']))" | tee -a gpurun_out/r5_long_share_b8.log
   done
 done
-timeout 900 python -m pytest tests/test_bench_shapes_gpu.py -q -p no:cacheprovider --durations=8 2>&1 | tail -14 > gpurun_out/r5_bench_shapes.log; tail -3 gpurun_out/r5_bench_shapes.log
