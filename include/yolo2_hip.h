@@ -427,9 +427,6 @@ int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
 int yolo2_debug_last_wgrad_plan(int *out8);
 /* 0 = transpose-read fragment gather (product), 1 = scalar reference gather (layout-proof, slow); process-wide, tests only */
 void yolo2_debug_set_wgrad_variant(int variant);
-/* A/B hook (process-wide): pixel rows a thread of yolo2_bn_leaky_fin / yolo2_bn_leaky_bwd_apply_fin keeps in flight: 1 (default) or 4
- * (bit-identical results; csrc/elementwise.hip bn_leaky_fin4_kernel, measured by scripts/bn_rows_in_flight.py) */
-int yolo2_debug_set_bn_rows_in_flight(int n);
 
 /* ---- on-device input pipeline: utils/data/__init__.py:50-109,162-175 + utils/preprocess.py:28-71 after JPEG
  * decode.  `src` holds the decoded uint8 RGB images back to back (any sizes); per image the caller supplies the

@@ -120,6 +120,9 @@ def test_forward_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     if name in ('conv18_19', 'conv20') and B == 16:
         # the launches that carry the benchmark: tap-fused 256x128 stream-K, one workgroup per CU ('stages' 9 = nine taps per halo image)
         assert plan['BM'] == 256 and plan['split'] == 2 and plan['waves'] == 8 and plan['stages'] == TAP_STAGES, plan
+    if name in ('conv18_19', 'conv20') and B == 8 and TAP_STAGES == 18 and 'YOLO2_PP_LONG_SHARE' not in os.environ:
+        # batch 8: 48 tiles cut into 5.3 shares of 27 / 81 K steps -- the long-share clause of the launch rule (profiles/r05_long_share_b8.txt)
+        assert (plan['BM'], plan['stages'], plan['split']) == (256, 18, 2), plan
     if name == 'conv13_15_17' and B == 16:
         # 88 tiles of 256 x 128, 24.75 K steps per workgroup, a tile cut into ~3 shares: stream-K on the ping-pong kernel (per-tap 128x128 stream-K with YOLO2_IGEMM_TAP=0)
         assert plan['split'] == 2 and (plan['BM'], plan['stages']) == ((256, 18) if TAP_STAGES == 18 else (128, 3)), plan

@@ -213,11 +213,10 @@ TAP_EPILOGUES = ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn']
 TAP_CASES = [(s_, 'pp', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
             [(s_, 'pp_tiles', e_) for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
 # Shapes with fewer K steps than CUs (odd sizes, partial tiles, 3 and 5 chunks, H != W).  A forced stream-K grid used to leave workgroups without
-# work whose flags an owner then waited for (a hang, found by these shapes); launch_conv now clamps the grid to the number of K steps.  The
-# fix was made after the round's last GPU-minute, so the shapes join the default list only once scripts/gpu_round5_first.sh has seen them green.
-if os.environ.get('YOLO2_TEST_TINY_TAP_SHAPES'):
-    _tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
-    TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles') for s_ in _tiny]
+# work whose flags an owner then waited for (a hang, found by these shapes); launch_conv clamps the grid to the number of K steps
+# (green on hardware: profiles/r05_tiny_tap_shapes.txt).
+_tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
+TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles') for s_ in _tiny]
 
 
 @pytest.mark.parametrize('shape,variant,epilogue', TAP_CASES, ids=['%s-%s-%s' % ('x'.join(map(str, c[0])), c[1], c[2]) for c in TAP_CASES])
@@ -767,20 +766,10 @@ def test_bn_leaky_fin_shift_is_read_only_across_thousands_of_workgroups(ops):
         ops.bn_leaky_pool_fin(yd, dev(part), rows, mm, mean, var, mm, mv, decay, g, b_, P, None, B, H, W, C, C, 1e-5, 0.1)
 
 
-@pytest.fixture(params=[1] + ([4] if os.environ.get('YOLO2_TEST_BN_ROWS4') else []), ids=lambda n: 'rows%d' % n)
-def bn_rows(request, ops):
-    """Pixel rows a thread of the un-pooled BN consumers keeps in flight (yolo2_debug_set_bn_rows_in_flight).  4 = the latency experiment of
-    elementwise.hip (bn_leaky_fin4_kernel / bn_bwd_apply_fin4_kernel), written after round 4's last GPU-minute: it joins the default
-    parameters once scripts/gpu_round5_first.sh has seen it green."""
-    ops.set_bn_rows_in_flight(request.param)
-    yield request.param
-    ops.set_bn_rows_in_flight(1)
-
-
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape,rows', [((2, 26, 26, 32), 256), ((4, 13, 13, 1024), 44), ((1, 52, 52, 64), 128), ((2, 26, 26, 512), 16), ((3, 8, 6, 8), 5),
                                         ((2, 14, 14, 256), 64)])
-def test_bn_consumers_with_folded_finalisation_vs_oracle(ops, shape, rows, mode, bn_rows):
+def test_bn_consumers_with_folded_finalisation_vs_oracle(ops, shape, rows, mode):
     """yolo2_bn_leaky_fin / _pool_fin / _bwd_apply_fin / _pool_bwd_apply_fin: the kernels that sum the partial rows in their own prologue,
     against the ORACLE (moments, moving averages, BN + leaky, pool, dgamma / dbeta, dY), plus the side clearing of another buffer."""
     B, H, W, C = shape
@@ -1094,39 +1083,6 @@ def test_head_decode_f32(ops, classes):
 
 
 NMS_CASES = ['sparse20', 'sparse80', 'dense', 'dense845', 'clustered', 'identical_ties', 'ties', 'at_threshold', 'all_below', 'zero_area']
-
-
-@pytest.mark.skipif(not os.environ.get('YOLO2_TEST_BN_ROWS4'), reason='experiment not yet run on hardware (scripts/gpu_round5_first.sh)')
-@pytest.mark.parametrize('shape', [(16, 13, 13, 1024), (16, 26, 26, 512), (3, 7, 5, 64), (2, 52, 52, 256)])
-def test_bn_rows_in_flight_4_is_bit_identical(ops, shape):
-    """The four-rows-in-flight forms of bn_leaky_fin / bn_leaky_bwd_apply_fin do the same arithmetic per element as the default kernels."""
-    B, H, W, C = shape
-    M, rows = B * H * W, 64
-    T = torch.bfloat16
-    g_ = torch.Generator(device='cuda').manual_seed(C + M)
-    y = (torch.randn(M * C, device='cuda', generator=g_) * 1.5).to(T)
-    da = torch.randn(M * C, device='cuda', generator=g_).to(T)
-    part = torch.randn(2 * 256 * C, device='cuda', generator=g_)
-    shift = torch.randn(C, device='cuda', generator=g_) * 0.1
-    gamma, beta = torch.rand(C, device='cuda', generator=g_) + 0.5, torch.randn(C, device='cuda', generator=g_) * 0.2
-    mean_b, var_b = torch.randn(C, device='cuda', generator=g_) * 0.1, torch.rand(C, device='cuda', generator=g_) + 0.5
-    res = {}
-    try:
-        for n in (1, 4):
-            ops.set_bn_rows_in_flight(n)
-            mean, var = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-            mm, mv = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
-            A = torch.zeros(M * C, dtype=T, device='cuda')
-            ops.bn_leaky_fin(y, part.abs(), rows, shift, mean, var, mm, mv, 0.999, gamma, beta, A, M, C, C, 1e-5, 0.1)
-            dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-            dY = torch.zeros(M * C, dtype=T, device='cuda')
-            ops.bn_leaky_bwd_apply_fin(da, C, y, mean_b, var_b, gamma, beta, part, rows, 256 * C, dg, db, dY, M, C, 1e-5, 0.1)
-            torch.cuda.synchronize()
-            res[n] = (mean, var, mm, mv, A, dg, db, dY)
-    finally:
-        ops.set_bn_rows_in_flight(1)
-    for a, b in zip(res[1], res[4]):
-        assert torch.equal(a, b)
 
 
 def _gpu_nms(ops, conf, mn, mx, thr, thr_iou):

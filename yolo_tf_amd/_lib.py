@@ -111,7 +111,6 @@ QUERIES = {
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_set_pp': (_i, [_i, _i, _i, _i]),
-    'yolo2_debug_set_bn_rows_in_flight': (_i, [_i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_conv2d_workspace_bytes': (ctypes.c_size_t, [_i] * 7),
     'yolo2_bn_workspace_bytes': (ctypes.c_size_t, [_i]),

@@ -727,7 +727,7 @@ static std::atomic<int> g_pp_grid{0};
 static std::atomic<int> g_pp_dmapos{y2_env_int("YOLO2_PP_SCHED", 2)};      // conv_pp.hip SCHED (2 = fragment reads, then the DMA pieces)
 static std::atomic<long> g_pp_min_steps{18};
 static std::atomic<long> g_pp_min_share{24};
-static const int g_pp_long_share = y2_env_int("YOLO2_PP_LONG_SHARE", 0);
+static const int g_pp_long_share = y2_env_int("YOLO2_PP_LONG_SHARE", 26);      // (0 = round 4's rule, for the A/B)
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
     if (grid != -1) g_pp_grid.store(grid, std::memory_order_relaxed);
     if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
@@ -808,8 +808,9 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             else if (tiles_t * 10 >= (long)tu.cus * 6 && tiles_t <= tu.cus) grid = (int)tiles_t;
             else if (can_stream && ((units_p >= g_pp_min_share.load(std::memory_order_relaxed) * tu.cus && tiles_t * 4 >= tu.cus) ||
                                     (bz.Y && M >= 8192 && units_p >= 10L * tu.cus) ||
-                                    // candidate (off unless YOLO2_PP_LONG_SHARE=26): long shares outweigh a tile cut into 5-8 of them -- batch 8,
-                                    // 48 tiles: conv20 forward 79 vs 119 us, conv18 41.2 vs 44.6 (profiles/r04_pp6_b8.txt); not yet run as the default
+                                    // long shares (>= 26 steps per workgroup) outweigh a tile cut into 5-8 of them -- batch 8, 48 tiles: conv20
+                                    // forward 79 vs 119 us, conv18 41.2 vs 44.6 (profiles/r04_pp6_b8.txt); the COCO-80 batch-8 step 2.84 -> 2.82 ms
+                                    // (profiles/r05_long_share_b8.txt)
                                     (g_pp_long_share > 0 && units_p >= (long)g_pp_long_share * tu.cus && tiles_t * 8 >= tu.cus))) grid = tu.cus;
             // every workgroup of a stream-K launch must hold at least one K step: an owner waits for the flag of EVERY workgroup whose range
             // lies inside its tile, and one without work never raises it (only a forced grid on a tiny problem gets here: the rule above

@@ -14,7 +14,6 @@
 #include "common.h"
 #include <stdlib.h>
 #include <stdarg.h>
-#include <atomic>
 
 // ------------------------------------------------------------------------------------------
 // error string (thread local) + misc ABI
@@ -1156,152 +1155,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T *__restri
     }
 }
 
-// ---- experiment (yolo2_debug_set_bn_rows_in_flight(4); default 1 = the two kernels above): the un-pooled forms with FOUR pixel rows per
-// thread requested before the prologue and four in flight through the loop.  The 13x13 / 26x26 launches move 5-11 MB each with one
-// 16-byte load + one prefetch per thread -- ~2 MB in flight over the chip, 1.3 TB/s, 8.6 / 11.9 us per launch in the single-stream trace
-// (profiles/r04_bench_kernel_trace_single_stream.md): latency, not bandwidth.  The grid already gives a thread four rows (slice_grid).
-// Same arithmetic, same order per element: results are bit-identical to the kernels above.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_leaky_fin4_kernel(const T *__restrict__ Y, const float *__restrict__ part, int rows, const float *__restrict__ shift,
-                                                            long Mstat, float *__restrict__ mean_out, float *__restrict__ var_out, float *__restrict__ mm,
-                                                            float *__restrict__ mv, float omd, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            T *__restrict__ A, long ML, int C, int lda, float eps, float alpha, float *__restrict__ zero,
-                                                            long zero_vec4) {
-    constexpr int N = Vec16<T>::N, R = 4;
-    const SliceMap sm(C, N);
-    __shared__ double sums[2][Y2_SLICE_MAX];
-    __shared__ float cst[3][Y2_SLICE_MAX];
-    const long step = (long)gridDim.x * sm.rpb;
-    long r = (long)blockIdx.x * sm.rpb + sm.row;
-    Vec16<T> v[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (r + k * step < ML) v[k] = ld16(Y + (r + k * step) * C + sm.cg * N);
-    slice_partial_sums(part, rows, (long)Y2_BN_PART_ROWS * C, C, sm, sums);
-    if (threadIdx.x < sm.cs) {
-        const int c = sm.c0 + threadIdx.x;
-        const double dm = sums[0][threadIdx.x] / (double)Mstat;
-        const double var = sums[1][threadIdx.x] / (double)Mstat - dm * dm;
-        const float fm = (float)((double)shift[c] + dm), fv = (float)(var > 0.0 ? var : 0.0);
-        cst[0][threadIdx.x] = fm;
-        cst[1][threadIdx.x] = (1.0f / sqrtf(fv + eps)) * gamma[c];
-        cst[2][threadIdx.x] = beta[c];
-        if (blockIdx.x == 0) {
-            mean_out[c] = fm;
-            var_out[c] = fv;
-            if (mm) {
-                mm[c] = mm[c] - (mm[c] - fm) * omd;
-                mv[c] = mv[c] - (mv[c] - fv) * omd;
-            }
-        }
-    }
-    __syncthreads();
-    float mu[N], sc[N], bt[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        mu[j] = cst[0][sm.lane * N + j];
-        sc[j] = cst[1][sm.lane * N + j];
-        bt[j] = cst[2][sm.lane * N + j];
-    }
-    grid_zero(zero, zero_vec4);
-    while (r < ML) {
-        const long rn = r + R * step;
-        Vec16<T> vn[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (rn + k * step < ML) vn[k] = ld16(Y + (rn + k * step) * C + sm.cg * N);
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const long rk = r + k * step;
-            if (rk < ML) {
-                Vec16<T> o;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    float z = (v[k].get(j) - mu[j]) * sc[j] + bt[j];
-                    o.set(j, fmaxf(z, alpha * z));
-                }
-                st16(A + rk * lda + sm.cg * N, o);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = vn[k];
-        r = rn;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fin4_kernel(const T *__restrict__ dA, int ldda, const T *__restrict__ Y, const float *__restrict__ mean,
-                                                                const float *__restrict__ var, const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                const float *__restrict__ part, int rows, long plane, float *__restrict__ dgamma,
-                                                                float *__restrict__ dbeta, T *__restrict__ dY, long ML, int C, float eps, float alpha,
-                                                                float *__restrict__ zero, long zero_vec4) {
-    constexpr int N = Vec16<T>::N, R = 4;
-    const SliceMap sm(C, N);
-    __shared__ double sums[2][Y2_SLICE_MAX];
-    __shared__ float cst[2][Y2_SLICE_MAX];
-    const long step = (long)gridDim.x * sm.rpb;
-    long r = (long)blockIdx.x * sm.rpb + sm.row;
-    Vec16<T> v[R], d[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k)
-        if (r + k * step < ML) {
-            v[k] = ld16(Y + (r + k * step) * C + sm.cg * N);
-            d[k] = ld16(dA + (r + k * step) * ldda + sm.cg * N);
-        }
-    slice_partial_sums(part, rows, plane, C, sm, sums);
-    if (threadIdx.x < sm.cs) {
-        const float dg = (float)sums[0][threadIdx.x], db = (float)sums[1][threadIdx.x];
-        cst[0][threadIdx.x] = dg;
-        cst[1][threadIdx.x] = db;
-        if (blockIdx.x == 0) {
-            dgamma[sm.c0 + threadIdx.x] = dg;
-            dbeta[sm.c0 + threadIdx.x] = db;
-        }
-    }
-    __syncthreads();
-    const float invM = 1.0f / (float)ML;
-    float mu[N], inv[N], ga[N], bt[N], dgm[N], dbm[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int c = sm.cg * N + j;
-        mu[j] = mean[c];
-        inv[j] = 1.0f / sqrtf(var[c] + eps);
-        ga[j] = gamma[c];
-        bt[j] = beta[c];
-        dgm[j] = cst[0][sm.lane * N + j] * invM;
-        dbm[j] = cst[1][sm.lane * N + j] * invM;
-    }
-    grid_zero(zero, zero_vec4);
-    while (r < ML) {
-        const long rn = r + R * step;
-        Vec16<T> vn[R], dn[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k)
-            if (rn + k * step < ML) {
-                vn[k] = ld16(Y + (rn + k * step) * C + sm.cg * N);
-                dn[k] = ld16(dA + (rn + k * step) * ldda + sm.cg * N);
-            }
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            const long rk = r + k * step;
-            if (rk < ML) {
-                Vec16<T> o;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    float xh = (v[k].get(j) - mu[j]) * inv[j];
-                    float z = (v[k].get(j) - mu[j]) * (inv[j] * ga[j]) + bt[j];
-                    float g = z >= 0.f ? d[k].get(j) : alpha * d[k].get(j);
-                    o.set(j, (ga[j] * inv[j]) * (g - dbm[j] - xh * dgm[j]));
-                }
-                st16(dY + rk * C + sm.cg * N, o);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) { v[k] = vn[k]; d[k] = dn[k]; }
-        r = rn;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // max pool 2x2 SAME
 // ------------------------------------------------------------------------------------------
@@ -2017,13 +1870,6 @@ extern "C" int yolo2_bn_leaky_pool_bwd_apply(const void *dP, int lddp, const uns
 }
 
 // ---- consumers with the finalisation in their prologue (kernels: bn_leaky_fin_kernel, bn_bwd_apply_fin_kernel)
-// A/B hook: pixel rows a thread of the un-pooled consumers keeps in flight (1 = default; 4 = bn_leaky_fin4_kernel / bn_bwd_apply_fin4_kernel)
-static std::atomic<int> g_bn_rows_in_flight{1};
-extern "C" int yolo2_debug_set_bn_rows_in_flight(int n) {
-    Y2_CHECK_ARG(n == 1 || n == 4);
-    g_bn_rows_in_flight.store(n, std::memory_order_relaxed);
-    return YOLO2_OK;
-}
 static bool fin_shape_ok(int rows, int C, int dtype) {
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     if (rows < 1 || C < vec || C % vec) return false;
@@ -2058,12 +1904,6 @@ extern "C" int yolo2_bn_leaky_fin(const void *Y, const float *bn_part, int rows,
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(lda % vec == 0);
     const dim3 grid = slice_grid(M, C, vec, 4, rows);
-    if (g_bn_rows_in_flight.load(std::memory_order_relaxed) == 4) {
-        Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin4_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, M, mean, var, moving_mean, moving_var,
-                          (float)(1.0 - decay), gamma, beta, (T *)A, M, C, lda, eps, alpha, zero, zero_floats / 4));
-        Y2_CHECK_LAUNCH();
-        return YOLO2_OK;
-    }
     Y2_DISPATCH_DTYPE(dtype, bn_leaky_fin_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)Y, bn_part, rows, shift, M, mean, var, moving_mean, moving_var,
                       (float)(1.0 - decay), gamma, beta, (T *)A, nullptr, nullptr, nullptr, 1, 1, (int)M, C, lda, eps, alpha, zero, zero_floats / 4));
     Y2_CHECK_LAUNCH();
@@ -2096,12 +1936,6 @@ extern "C" int yolo2_bn_leaky_bwd_apply_fin(const void *dA, int ldda, const void
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
     Y2_CHECK_ARG(ldda % vec == 0);
     const dim3 grid = slice_grid(M, C, vec, 4, rows);
-    if (g_bn_rows_in_flight.load(std::memory_order_relaxed) == 4) {
-        Y2_DISPATCH_DTYPE(dtype, bn_bwd_apply_fin4_kernel<T><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, (const T *)Y, mean, var, gamma, beta, part, rows,
-                          plane_stride, dgamma, dbeta, (T *)dY, M, C, eps, alpha, zero, zero_floats / 4));
-        Y2_CHECK_LAUNCH();
-        return YOLO2_OK;
-    }
     Y2_DISPATCH_DTYPE(dtype, bn_bwd_apply_fin_kernel<T, false><<<grid, 256, 0, (hipStream_t)stream>>>((const T *)dA, ldda, nullptr, (const T *)Y, mean, var, gamma, beta, part, rows,
                       plane_stride, dgamma, dbeta, (T *)dY, 1, 1, (int)M, C, eps, alpha, zero, zero_floats / 4));
     Y2_CHECK_LAUNCH();

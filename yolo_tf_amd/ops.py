@@ -346,13 +346,6 @@ def set_pp(grid=-1, dmapos=-1, min_steps=-1, min_share=-1):
     _lib.load().yolo2_debug_set_pp(int(grid), int(dmapos), int(min_steps), int(min_share))
 
 
-def set_bn_rows_in_flight(n):
-    """A/B hook: 1 (default) or 4 pixel rows per thread in flight in bn_leaky_fin / bn_leaky_bwd_apply_fin (bit-identical results)."""
-    rc = _lib.load().yolo2_debug_set_bn_rows_in_flight(int(n))
-    if rc != 0:
-        raise ValueError('rows in flight: 1 or 4')
-
-
 def last_wgrad_plan():
     out = (ctypes.c_int * 8)()
     _lib.load().yolo2_debug_last_wgrad_plan(out)
