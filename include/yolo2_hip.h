@@ -48,6 +48,11 @@ const char *yolo2_last_error(void);
 uint32_t yolo2_crc32c(const void *data, size_t n, uint32_t crc);
 /* releases the library-owned stream-K flag pools (after synchronising their devices); any later call re-creates them */
 int yolo2_shutdown(void);
+/* Synchronises `stream` and reports errors only the device can detect: a stream-K convolution whose tile owner gave up waiting for a
+ * partner workgroup's partial tile (the wait is bounded at 2 s; conv_shared.h y2_sk_wait_and_clear).  YOLO2_E_LAUNCH then means that
+ * convolution outputs produced since the previous check are invalid; the flag pool is reset and the process may continue.  The counterpart
+ * of the reference surfacing failures as exceptions instead of hanging (utils/postprocess.py:22-35 asserts, detect.py:70 check_numerics). */
+int yolo2_check_async_errors(void *stream);
 
 /* ---- workspace sizes, in bytes, of every entry that takes caller-owned scratch (`ws`): pure host queries ----------------
  * yolo2_conv2d_workspace_bytes: the largest scratch any variant of yolo2_conv2d_ws / _bn / _bias_leaky can use for the
@@ -424,6 +429,9 @@ int yolo2_debug_set_igemm_tap(int mode);
  * an order the library was not built with sends the layer to the per-tap kernels).  min_steps / min_share: the rule's gates (K steps
  * per tile, K steps per workgroup).  A negative argument keeps the current value. */
 int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
+/* tests: the stream-K owners' wait limit in microseconds (0 = the default, 2 s); unclamped != 0 lets a grid forced through yolo2_debug_set_pp
+ * exceed the number of K steps -- a partition no owner can be served by, which must end in yolo2_check_async_errors() == YOLO2_E_LAUNCH */
+int yolo2_debug_set_streamk_wait_us(int us, int unclamped);
 int yolo2_debug_last_wgrad_plan(int *out8);
 /* 0 = transpose-read fragment gather (product), 1 = scalar reference gather (layout-proof, slow); process-wide, tests only */
 void yolo2_debug_set_wgrad_variant(int variant);

@@ -196,6 +196,30 @@ def test_optimizer_sharding_equals_replicated_update_gloo_world2(tmp_path, grad_
     assert open(out).read() == 'ok'
 
 
+def test_shard_collective_errors_propagate_instead_of_switching_collectives(monkeypatch):
+    """The reduce-scatter / all-gather path is chosen from the backend, once; an error raised by the collective itself (a rank-local RCCL
+    failure) must reach the caller -- it used to be caught and answered with an all-reduce on that rank only, while its peers sat in
+    reduce-scatter: mismatched collectives, a hang instead of a message."""
+    from yolo_tf_amd import parallel
+    g = torch.ones(256)
+    red = parallel.GradReducer(g, [(0, 256)], bucket_mb=1, shard_params=torch.zeros(256), rank=0)
+    assert red.native_shard_collectives is False                 # no process group / gloo: the all-reduce emulation
+    calls = []
+
+    def boom(*a, **k):
+        calls.append('native')
+        raise RuntimeError('NCCL error: unhandled system error (injected)')
+    monkeypatch.setattr(parallel.dist, 'reduce_scatter_tensor', boom)
+    monkeypatch.setattr(parallel.dist, 'all_gather_into_tensor', boom)
+    monkeypatch.setattr(parallel.dist, 'all_reduce', lambda *a, **k: calls.append('all_reduce'))
+    red.native_shard_collectives = True                          # what dist.get_backend(group) == 'nccl' selects
+    with pytest.raises(RuntimeError, match='injected'):
+        red._reduce_scatter(g, 0, 0, 128, 256)
+    with pytest.raises(RuntimeError, match='injected'):
+        red._all_gather(g, 0, 0, 128, 256)
+    assert calls == ['native', 'native']                         # no silent second collective
+
+
 def test_single_process_reducer_is_a_noop():
     from yolo_tf_amd.parallel import GradReducer
     g = torch.ones(100)

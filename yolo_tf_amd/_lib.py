@@ -95,6 +95,8 @@ SIGNATURES = {
     'yolo2_cast_f32_bf16': [_p, _p, _l, _p],
     'yolo2_cast_bf16_f32': [_p, _p, _l, _p],
     'yolo2_debug_occupy': [_i, _p, _p, _i, _p],
+    'yolo2_check_async_errors': [_p],
+    'yolo2_debug_set_streamk_wait_us': [_i, _i],
 }
 
 # host queries / diagnostics: (restype, argtypes); bound in load() next to the status-returning entries above

@@ -27,6 +27,9 @@ def _layout(engine):
 def save(logdir, session, keep=5):
     """Writes model.ckpt-<step>.npz atomically and keeps the ``keep`` most recent files ([TF-sem] tf.train.Saver
     max_to_keep=5, which slim.learning.train's default saver uses; each file is ~0.8 GB with Adam slots)."""
+    if not getattr(session, 'optimizer_state_complete', True):
+        raise RuntimeError('optimizer sharding: this rank holds the optimizer slots of its own shards only; call '
+                           'session.gather_optimizer_state() on EVERY rank before saving (train.py does)')
     os.makedirs(logdir, exist_ok=True)
     e = session.engine
     data = {'var/' + k: v for k, v in e.get_variables().items()}

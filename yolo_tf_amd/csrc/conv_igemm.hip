@@ -74,7 +74,7 @@ template <> struct Mma<float> {
 
 // (Timing-ablation hooks -- no epilogue / no MFMA / no fragment reads / no DMA builds -- live in scripts/experiments/conv_igemm_ablation_hooks.patch,
 // applied to a COPY of this file by scripts/abl_build.sh; the product source carries none.)
-#define Y2_STREAM_FLAG_WORDS 1024     // stream-K: one flag word per workgroup (library-owned pool); the workspace holds one f32 tile slot each
+// (Y2_STREAM_FLAG_WORDS, conv_shared.h: one stream-K flag word per workgroup in a library-owned pool; the workspace holds one f32 tile slot each)
 // SPLITK: 0 = one workgroup per output tile; 1 = K loop sliced over gridDim.y; 2 = stream-K: gridDim.x workgroups (one per
 // CU) share the flat (tile, K step) space in equal contiguous ranges.  1 and 2 accumulate f32 partial tiles with atomics.
 template <typename T, int BN, int WGN, int NSTAGE, int KS, int SPLITK, bool CTAIL, int CH = 4, int NW = 4, int BMv = 128, bool BNBWD = false>
@@ -352,10 +352,7 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             const int G = gridDim.x;
             long covered = su;
             for (int p = wx + 1; covered < tile_end; ++p) {
-                if (tid == 0) {
-                    while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exactly one consumer per flag
-                }
+                if (tid == 0) y2_sk_wait_and_clear(flags, p);      // (bounded: conv_shared.h)
                 __syncthreads();
                 const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
@@ -596,18 +593,64 @@ static const Tune &tune() {   // shape-selection constants (each the measured be
 static std::mutex g_flag_mutex;
 static unsigned *g_flag_pool[64] = {nullptr};
 static unsigned g_flag_counter[64] = {0};
+static std::atomic<unsigned> g_sk_wait_ticks{0};       // 0 = Y2_SK_DEFAULT_WAIT_TICKS (tests shorten it: yolo2_debug_set_streamk_wait_us)
+static std::atomic<int> g_sk_unclamped{0};             // tests only: lets a forced grid exceed the number of K steps (the partition bug the wait bound exists for)
 static unsigned *stream_flags() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_flag_mutex);
     if (!g_flag_pool[dev]) {
         unsigned *p = nullptr;
-        const size_t bytes = (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_WORDS * sizeof(unsigned);
+        const size_t bytes = (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_STRIDE * sizeof(unsigned);
         if (hipMalloc((void **)&p, bytes) != hipSuccess) return nullptr;
         if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
         g_flag_pool[dev] = p;
     }
-    return g_flag_pool[dev] + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_WORDS;
+    return g_flag_pool[dev] + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_STRIDE;
+}
+// Synchronises `stream` and reports what only the device can know: a stream-K owner that gave up waiting for a partner's partial tile
+// (y2_sk_wait_and_clear).  The pool is re-zeroed so that the process can go on, but every result since the previous check is suspect.
+extern "C" int yolo2_check_async_errors(void *stream) {
+    int dev = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        yolo2_set_error("yolo2_check_async_errors: HIP error: %s", hipGetErrorString(hipGetLastError()));
+        return YOLO2_E_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lock(g_flag_mutex);
+    if (!g_flag_pool[dev]) return YOLO2_OK;
+    unsigned status[Y2_STREAM_FLAG_SETS] = {0};
+    if (hipMemcpy2D(status, sizeof(unsigned), g_flag_pool[dev] + Y2_STREAM_FLAG_WORDS, Y2_STREAM_FLAG_STRIDE * sizeof(unsigned), sizeof(unsigned),
+                    Y2_STREAM_FLAG_SETS, hipMemcpyDeviceToHost) != hipSuccess) {
+        yolo2_set_error("yolo2_check_async_errors: reading the stream-K status words failed");
+        return YOLO2_E_LAUNCH;
+    }
+    unsigned gave_up = 0;
+    for (int i = 0; i < Y2_STREAM_FLAG_SETS; ++i) gave_up += status[i];
+    if (!gave_up) return YOLO2_OK;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(g_flag_pool[dev], 0, (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_STRIDE * sizeof(unsigned));
+    const unsigned ticks = g_sk_wait_ticks.load(std::memory_order_relaxed);
+    for (int i = 0; ticks && i < Y2_STREAM_FLAG_SETS; ++i)
+        (void)hipMemcpy(g_flag_pool[dev] + (size_t)i * Y2_STREAM_FLAG_STRIDE + Y2_STREAM_FLAG_WORDS + 1, &ticks, sizeof(ticks), hipMemcpyHostToDevice);
+    yolo2_set_error("stream-K hand-off: %u wait(s) for a partner workgroup's partial tile gave up; convolution outputs since the last check are invalid", gave_up);
+    return YOLO2_E_LAUNCH;
+}
+// tests: wait limit of the stream-K owners in microseconds (0 = default, 2 s) and the grid clamp (unclamped != 0 lets yolo2_debug_set_pp force
+// more workgroups than K steps -- an unserviceable partition)
+extern "C" int yolo2_debug_set_streamk_wait_us(int us, int unclamped) {
+    if (us < 0) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: us < 0"); return YOLO2_E_ARG; }
+    const unsigned ticks = (unsigned)us * 100u;
+    g_sk_wait_ticks.store(ticks, std::memory_order_relaxed);
+    g_sk_unclamped.store(unclamped, std::memory_order_relaxed);
+    if (!stream_flags()) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: no flag pool"); return YOLO2_E_LAUNCH; }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_flag_mutex);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < Y2_STREAM_FLAG_SETS; ++i)
+        if (hipMemcpy(g_flag_pool[dev] + (size_t)i * Y2_STREAM_FLAG_STRIDE + Y2_STREAM_FLAG_WORDS + 1, &ticks, sizeof(ticks), hipMemcpyHostToDevice) != hipSuccess)
+            return YOLO2_E_LAUNCH;
+    return YOLO2_OK;
 }
 extern "C" int yolo2_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_flag_mutex);
@@ -815,7 +858,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             // every workgroup of a stream-K launch must hold at least one K step: an owner waits for the flag of EVERY workgroup whose range
             // lies inside its tile, and one without work never raises it (only a forced grid on a tiny problem gets here: the rule above
             // asks for >= 10 steps per workgroup)
-            if (grid > units_p) grid = (int)units_p;
+            if (grid > units_p && !g_sk_unclamped.load(std::memory_order_relaxed)) grid = (int)units_p;
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];

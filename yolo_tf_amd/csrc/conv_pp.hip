@@ -469,10 +469,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             const long tile_end = su - kt_end + nk;
             long covered = su;
             for (int p = wx + 1; covered < tile_end; ++p) {
-                if (tid == 0) {
-                    while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-                    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (tid == 0) y2_sk_wait_and_clear(flags, p);      // (bounded: conv_shared.h)
                 __syncthreads();
                 const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
@@ -668,7 +665,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         if (W <= 27) { if (bwd) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(false, 312, 5, SCv); }             \
         else { if (bwd) Y2P_LAUNCH(true, 368, 4, SCv); else Y2P_LAUNCH(false, 368, 4, SCv); }                     \
         return 0;
-    if (W > 55 || (long)grid > (long)((M + Y2P_BM - 1) / Y2P_BM) * NT * (Cp / 64) * 9) return 1;      // (a workgroup without a K step would never raise its flag)
+    if (W > 55) return 1;      // (the grid <= K steps clamp is launch_conv's: a workgroup without a K step never raises its flag, and its owner's bounded wait gives up)
     const bool bwd = bz.Y != nullptr || (sched & 32) != 0;      // (+32, measurements only: the BN-backward instantiation without its sums)
 #ifdef Y2P_EXPERIMENTS      // (scripts/pp_experiments_build.sh: the SCHED variants and timing ablations behind profiles/r04_pp*.txt)
 #define Y2P_ABL_CASE(SCv)                                                                                          \

@@ -4,6 +4,34 @@
 
 #define Y2_OOB 0x80000000u   // any offset >= num_records makes the buffer DMA return zeros
 
+// Stream-K hand-off flags (conv_igemm.hip owns the pool): one set = Y2_STREAM_FLAG_WORDS flag words -- one per workgroup -- followed by a
+// status block: word [WORDS] counts waits that gave up, word [WORDS + 1] is the wait limit in wall-clock ticks (100 MHz; 0 = default).
+#define Y2_STREAM_FLAG_WORDS 1024
+#define Y2_STREAM_FLAG_STRIDE (Y2_STREAM_FLAG_WORDS + 64)
+#define Y2_SK_DEFAULT_WAIT_TICKS 200000000u      // 2 s: five orders of magnitude above the longest legitimate wait (a partner's tail segment, < 100 us)
+#if defined(__HIP_DEVICE_COMPILE__)
+// The owner of a stream-K tile waits for the flag of partner workgroup p (called by ONE lane) and clears it.  The wait is bounded: a partition
+// bug (a workgroup without work never raises its flag -- the hang behind launch_conv's grid clamp) or a lost partner must surface as an error,
+// not as a hung device.  On a time-out the launch's results are wrong by construction; the status word makes yolo2_check_async_errors() (and every
+// later stream-K launch of this process) return YOLO2_E_LAUNCH.  The fast path (flag already up) costs one load, as before.
+__device__ __forceinline__ void y2_sk_wait_and_clear(unsigned *flags, int p) {
+    if (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        const unsigned cfg = __hip_atomic_load(flags + Y2_STREAM_FLAG_WORDS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long limit = cfg ? cfg : Y2_SK_DEFAULT_WAIT_TICKS, t0 = wall_clock64();
+        while (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > limit) {
+                __hip_atomic_fetch_add(flags + Y2_STREAM_FLAG_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exactly one consumer per flag
+}
+#else
+__device__ inline void y2_sk_wait_and_clear(unsigned *, int) {}      // (host pass of a __global__ body)
+#endif
+
 // Data-gradient launches whose output IS the gradient dA of a batch-normalised producer layer (a = leaky(bn(y))) can reduce that
 // layer's BN + leaky backward sums in their epilogue: Y non-NULL selects it.  Per output element dz = dA * leaky'(z),
 // xhat = (y - mean) * rstd; the tile adds its columns' sum(dz * xhat) [plane 0] and sum(dz) [plane 1] to the partial rows the

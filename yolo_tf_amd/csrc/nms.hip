@@ -18,6 +18,7 @@
 // Finally the removed boxes' scores in column c are zeroed in place, as the reference mutates
 // its input.
 #include "common.h"
+#include <atomic>
 #include <stdlib.h>
 #pragma clang fp contract(off)
 
@@ -174,19 +175,24 @@ extern "C" int yolo2_nms(float *conf, const float *xy_min, const float *xy_max, 
     int NP = 2;                       // (even: keeps the 8-byte words behind perm[] aligned)
     while (NP < N) NP <<= 1;
     const size_t nchunks = ((size_t)N + 63) / 64;
-    (void)nchunks;
     const size_t lds = sizeof(float) * 3 * (size_t)N + 16 + sizeof(float) * 4 * (size_t)N + sizeof(int) * ((size_t)NP + 256);      // <= 129 KB at N = 4096
+    // the overlap-bitmask rows of a candidate group (8 bytes x (64 x nchunks + 1)) are laid over the sort buffers key / perm / cnt
+    // (4 N + 4 NP + 1024 bytes) once the sort is done: the overlay must fit
+    if (8 * (64 * nchunks + 1) > 4 * (size_t)N + 4 * (size_t)NP + 1024) {
+        yolo2_set_error("nms: bitmask rows (%zu bytes) do not fit the sort buffers they are laid over", 8 * (64 * nchunks + 1));
+        return YOLO2_E_ARG;
+    }
     if (lds > 64 * 1024) {
         // the attribute is per device: remember what each device of this process has been raised to (a second GPU never inherited the first one's limit)
-        static size_t lds_set[64] = {0};
+        static std::atomic<size_t> lds_set[64];      // (atomic: two host threads may call yolo2_nms at once; zero-initialised)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = -1;
-        if (dev < 0 || lds > lds_set[dev]) {
+        if (dev < 0 || lds > lds_set[dev].load(std::memory_order_relaxed)) {
             if (hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 yolo2_set_error("nms: cannot reserve %zu bytes of LDS", lds);
                 return YOLO2_E_LAUNCH;
             }
-            if (dev >= 0) lds_set[dev] = lds;
+            if (dev >= 0) lds_set[dev].store(lds, std::memory_order_relaxed);
         }
     }
     nms_kernel<<<B * C, 256, lds, st>>>(conf, (const float *)ws, xy_min, xy_max, order_out, N, C, threshold, threshold_iou, NP);

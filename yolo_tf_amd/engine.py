@@ -520,8 +520,9 @@ class Engine(object):
                     pb, ldp = self.act[pool['out']]
                     if self.training:
                         part = self.parts.acquire(2 * 256 * 32)
-                        ops.first_layer_stats(xb, st['Ffwd'], B, x.h, x.w, mmean, self.parts.bufs[part])
-                        ops.bn_finalize(self.parts.bufs[part], mmean, M, 32, st['mean'], st['var'], mmean, mvar, BN_DECAY)
+                        shift = self.svar[op['moving_mean'].name]       # this step's snapshot, like every other layer: never aliases the updated moving mean
+                        ops.first_layer_stats(xb, st['Ffwd'], B, x.h, x.w, shift, self.parts.bufs[part])
+                        ops.bn_finalize(self.parts.bufs[part], shift, M, 32, st['mean'], st['var'], mmean, mvar, BN_DECAY)
                         self.parts.consumed(part, cleared=True)
                         mean, var = st['mean'], st['var']
                     else:

@@ -346,6 +346,17 @@ def set_pp(grid=-1, dmapos=-1, min_steps=-1, min_share=-1):
     _lib.load().yolo2_debug_set_pp(int(grid), int(dmapos), int(min_steps), int(min_share))
 
 
+def check_async_errors():
+    """Synchronises the current stream; raises RuntimeError when a stream-K tile owner gave up waiting for a partner (include/yolo2_hip.h
+    yolo2_check_async_errors): errors surface, the device never hangs."""
+    call('yolo2_check_async_errors', _stream())
+
+
+def set_streamk_wait_us(us=0, unclamped=False):
+    """Test hook: wait limit of the stream-K owners (0 = default 2 s) and the grid <= K-steps clamp."""
+    call('yolo2_debug_set_streamk_wait_us', int(us), int(bool(unclamped)))
+
+
 def last_wgrad_plan():
     out = (ctypes.c_int * 8)()
     _lib.load().yolo2_debug_last_wgrad_plan(out)

@@ -118,6 +118,8 @@ class GradReducer(object):
         self.shard = shard_params is not None
         self.rank = (dist.get_rank(group) if dist.is_initialized() else 0) if rank is None else rank
         self.update_fn = None
+        # reduce-scatter / all-gather into one tensor exist on RCCL ("nccl"); every other backend takes the all-reduce emulation
+        self.native_shard_collectives = bool(dist.is_initialized() and dist.get_backend(group) == 'nccl')
 
     def begin(self):
         self.next_bucket = 0
@@ -142,20 +144,23 @@ class GradReducer(object):
     # ---- optimizer sharding: reduce-scatter -> update own shard -> all-gather, per bucket
     def _reduce_scatter(self, buf, s, own_lo, own_hi, send):
         """buf[own_lo:own_hi] = sum over ranks of their buf[own_lo:own_hi]; [s, send) = world equal shards.  In place (the output is this
-        rank's slice of the input).  Backends without reduce-scatter (gloo, the CPU tests) all-reduce the range: same values."""
+        rank's slice of the input).  The path is chosen ONCE from the group's backend (``self.native_shard_collectives``), never from a caught
+        exception: a rank-local RCCL error must propagate (and be agreed across ranks by the caller, like every other rank-local
+        error), not make that one rank issue a different collective than its peers.  Backends without reduce-scatter into a tensor
+        (gloo: the CPU tests) all-reduce the range -- same values."""
         if send == s:
             return
-        try:
+        if self.native_shard_collectives:
             dist.reduce_scatter_tensor(buf[own_lo:own_hi], buf[s:send], op=dist.ReduceOp.SUM, group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             dist.all_reduce(buf[s:send], op=dist.ReduceOp.SUM, group=self.group)
 
     def _all_gather(self, buf, s, own_lo, own_hi, send):
         if send == s:
             return
-        try:
+        if self.native_shard_collectives:
             dist.all_gather_into_tensor(buf[s:send], buf[own_lo:own_hi], group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             # gloo (tests): no all-gather into one tensor, none at all for device tensors -- sum of zero-padded shards instead
             tmp = torch.zeros_like(buf[s:send])
             tmp[own_lo - s:own_hi - s].copy_(buf[own_lo:own_hi])

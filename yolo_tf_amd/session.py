@@ -72,6 +72,13 @@ class TrainSession(object):
         # [mi355x] shard_optimizer: reduce-scatter / update 1/world / all-gather instead of all-reduce + the replicated optimizer pass
         # (parallel.GradReducer); per-tensor clipping needs every complete gradient first, so it keeps the replicated form
         self.shard_optimizer = bool(shard_optimizer) and world_size > 1 and self.gradient_clip <= 0
+        if shard_optimizer and world_size > 1 and not self.shard_optimizer:
+            import logging
+            logging.getLogger(__name__).warning('[mi355x] shard_optimizer is ignored: gradient_clip = %g needs every complete gradient, the update stays replicated',
+                                                self.gradient_clip)
+        # False between a sharded update and gather_optimizer_state(): this rank's optimizer slots then hold other ranks' shards from an
+        # earlier gather (or their initial values) -- checkpoint.save / tf_checkpoint.save refuse to write them
+        self.optimizer_state_complete = True
         self.reducer = GradReducer(e.grads, list(e.param_offsets.values()), bucket_mb, grad_dtype=grad_dtype, timing=comm_timing,
                                    shard_params=e.params if self.shard_optimizer else None) if world_size > 1 else None
         if world_size > 1:
@@ -150,6 +157,7 @@ class TrainSession(object):
             self.reducer.finish(wait=True)
             self._deferred = False
             self._sharded_pending = False
+            self.optimizer_state_complete = False      # own shards only, until gather_optimizer_state()
             self.global_step += 1
             e._filters_dirty = True
         elif self.reducer is not None and getattr(self, '_deferred', False):
@@ -175,6 +183,7 @@ class TrainSession(object):
         if self.reducer is not None and self.shard_optimizer:
             self.reducer.shard = True
             self.reducer.gather_slots(self.optimizer.slots)
+        self.optimizer_state_complete = True
 
     def step(self, images, labels=None):
         if labels is not None:
@@ -188,6 +197,7 @@ class TrainSession(object):
         if getattr(self, '_objectives_pending', None):
             ops.loss_objectives(self.loss_ws, self.objectives_dev, self.B, self._objectives_pending[0], self._objectives_pending[1], self.A)
             self._objectives_pending = None
+        ops.check_async_errors()           # device-detected failures (a stream-K hand-off that gave up) become exceptions here
         vals = self.objectives_dev.cpu().numpy().astype(np.float64)
         out = {k: float(v) for k, v in zip(OBJECTIVE_KEYS, vals)}
         out['regularization'] = float(self.engine.reg_loss.item())        # slim.l2_regularizer terms (YOLO v1 fully connected layers; 0 for yolo2)

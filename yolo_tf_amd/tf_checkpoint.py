@@ -327,6 +327,9 @@ def save(logdir, session, step=None, keep=5):
     """Writes ``<logdir>/model.ckpt-<step>`` (+ the ``checkpoint`` state file) with the reference's variable names, global_step and
     the Adam slots, i.e. what its tf.train.Saver would hold for this model.  Keeps the ``keep`` most recent checkpoints
     ([TF-sem] tf.train.Saver max_to_keep=5: each is ~0.8 GB with Adam slots) and lists them in all_model_checkpoint_paths."""
+    if not getattr(session, 'optimizer_state_complete', True):
+        raise RuntimeError('optimizer sharding: this rank holds the optimizer slots of its own shards only; call '
+                           'session.gather_optimizer_state() on EVERY rank before saving (train.py does)')
     e = session.engine
     step = session.global_step if step is None else step
     tensors = dict(e.get_variables())
