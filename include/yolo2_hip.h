@@ -433,8 +433,15 @@ int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
  * exceed the number of K steps -- a partition no owner can be served by, which must end in yolo2_check_async_errors() == YOLO2_E_LAUNCH */
 int yolo2_debug_set_streamk_wait_us(int us, int unclamped);
 int yolo2_debug_last_wgrad_plan(int *out8);
-/* 0 = transpose-read fragment gather (product), 1 = scalar reference gather (layout-proof, slow); process-wide, tests only */
+/* process-wide, tests / A-B only: 0 = product rule (bf16 3x3 layers: the row-of-taps kernel of csrc/conv_wgrad3.hip; everything else: the per-tap
+ * transpose-read kernel of csrc/conv_wgrad.hip); 1 = scalar reference gather (layout-proof, slow); 2 = the per-tap kernel for every shape
+ * (round 4's path); 10 + v = variant v (0..2) of the row-of-taps kernel for every shape it can take.  YOLO2_WGRAD_VARIANT sets the initial value. */
 void yolo2_debug_set_wgrad_variant(int variant);
+/* host-side plan of the row-of-taps filter-gradient kernel for a shape on a device with `cus` compute units (force_variant < 0: by rule):
+ * out9 = {variant (-1: not taken), pixel ranges, padded pixels per range, workgroups, XCD mapping, plain stores, channel tile, filter tile, waves} */
+int yolo2_debug_wgrad_row_plan(int B, int H, int W, int Cin, int Cout, int cus, int force_variant, int *out9);
+/* the multiply-high division constants of that kernel's DMA address arithmetic: floor(q / d) == (uint64(q) * m >> 32) >> s for 0 <= q < 2^31 */
+int yolo2_debug_magic_u32(unsigned d, unsigned *m, unsigned *s);
 
 /* ---- on-device input pipeline: utils/data/__init__.py:50-109,162-175 + utils/preprocess.py:28-71 after JPEG
  * decode.  `src` holds the decoded uint8 RGB images back to back (any sizes); per image the caller supplies the

@@ -195,3 +195,88 @@ def test_stream_k_grid_larger_than_the_k_steps_leaves_workgroups_empty():
     and workgroup 29 has nothing to park."""
     segs = _streamk_segments(1, 9, 256)
     assert [w for w, s in enumerate(segs) if s][:2] == [28, 56] and not segs[29]
+
+
+# ---- row-of-taps filter-gradient kernel (csrc/conv_wgrad3.hip): host-side pieces checked without a GPU
+def _magic(q, d):
+    import ctypes
+    m, s = ctypes.c_uint(0), ctypes.c_uint(0)
+    assert q('yolo2_debug_magic_u32', d, ctypes.byref(m), ctypes.byref(s)) == 0
+    return int(m.value), int(s.value)
+
+
+@pytest.mark.parametrize('d', [2, 3, 4, 5, 7, 8, 11, 13, 14, 16, 20, 21, 27, 32, 39, 53, 64, 77, 105, 128, 209, 256, 417, 609, 1000, 65535])
+def test_magic_division_is_exact_below_2_to_31(q, d):
+    """floor(x / d) == (x * m >> 32) >> s: every x below 2^24 (the kernel's padded positions are), the boundaries up to 2^31 and random values."""
+    m, s = _magic(q, d)
+    assert m < 2 ** 32
+    x = np.arange(0, 1 << 24, dtype=np.uint64)
+    assert np.array_equal(((x * np.uint64(m)) >> np.uint64(32)) >> np.uint64(s), x // np.uint64(d))
+    rng = np.random.RandomState(d)
+    edge = np.concatenate([np.arange(1, 4000, dtype=np.uint64) * np.uint64(d) - np.uint64(1), np.arange(1, 4000, dtype=np.uint64) * np.uint64(d),
+                           (np.uint64(2 ** 31 - 1) - np.arange(0, 4000, dtype=np.uint64)), rng.randint(0, 2 ** 31, 200000).astype(np.uint64)])
+    edge = edge[edge < np.uint64(2 ** 31)]
+    assert np.array_equal(((edge * np.uint64(m)) >> np.uint64(32)) >> np.uint64(s), edge // np.uint64(d))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 13, 13, 8, 8), (3, 5, 7, 4, 6), (1, 2, 2, 3, 2), (2, 6, 15, 5, 3)])
+def test_padded_pixel_index_decomposition_equals_the_filter_gradient(q, B, H, W, Cin, Cout):
+    """The kernel's algebra, restated with NumPy: over the padded index q (row pitch W + 1, one zero column per image row), with X rows
+    taken dh image rows away through the source address (zeros outside the image) and the three taps of a kernel row read at q - 1, q, q + 1,
+    sum_q Xs[q + dw] dYp[q] is the SAME-padded 3x3 filter gradient -- no (pixel, tap) mask anywhere.  The source decomposition uses the
+    library's magic constants the way the kernel's DMA address arithmetic does."""
+    from oracle import yolo2_ref as R
+    rng = np.random.RandomState(B * 100 + H * 10 + W)
+    x = rng.randn(B, H, W, Cin).astype(np.float32)
+    dy = rng.randn(B, H, W, Cout).astype(np.float32)
+    ref = R.conv2d_wgrad(x, dy, 3, 3)
+    mW, sW = _magic(q, W + 1)
+    mH, sH = _magic(q, H)
+    Mp, halo = B * H * (W + 1), 4
+    xf, dyf = x.reshape(B * H * W, Cin), dy.reshape(B * H * W, Cout)
+    got = np.zeros((3, 3, Cin, Cout), np.float64)
+    for dh in (-1, 0, 1):
+        # what the DMA stages: X rows for padded positions -halo .. Mp + halo, dY rows for 0 .. Mp
+        xs = np.zeros((Mp + 2 * halo, Cin))
+        for i in range(Mp + 2 * halo):
+            qq = (i - halo) & 0xffffffff                                   # unsigned wrap below zero, as in the kernel
+            Rr = ((qq * mW) >> 32) >> sW
+            c = (qq - Rr * (W + 1)) & 0xffffffff
+            r = Rr - (((Rr * mH) >> 32) >> sH) * H
+            if qq < Mp and c < W and 0 <= r + dh < H:
+                xs[i] = xf[qq - Rr + dh * W]
+        dyp = np.zeros((Mp, Cout))
+        for qq in range(Mp):
+            Rr = ((qq * mW) >> 32) >> sW
+            c = qq - Rr * (W + 1)
+            if c < W:
+                dyp[qq] = dyf[qq - Rr]
+        for dw in (-1, 0, 1):
+            got[dh + 1, dw + 1] = xs[halo + dw:halo + dw + Mp].T @ dyp
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_row_kernel_plans(q):
+    """Variant and pixel-range rule of the row-of-taps kernel on a 256-CU device: 13x13 stages store (one range, plain stores, L2-stationary
+    order), the split layers keep one workgroup per CU at most, every range is whole ring turns, ranges cover the padded pixels."""
+    import ctypes
+    def plan(B, H, cin, cout, cus=256, force=-1):
+        out = (ctypes.c_int * 9)()
+        assert q('yolo2_debug_wgrad_row_plan', B, H, H, cin, cout, cus, force, out) == 0
+        return dict(zip(('variant', 'ranges', 'qchunk', 'blocks', 'remap', 'direct', 'BC', 'BN', 'waves'), list(out)))
+    for B in (4, 8, 16, 32):
+        for H, cin, cout in ((13, 512, 1024), (13, 1024, 1024), (13, 3072, 1024)):
+            p = plan(B, H, cin, cout)
+            assert (p['variant'], p['ranges'], p['direct'], p['remap'], p['BC'], p['BN']) == (2, 1, 1, 2, 64, 128), p
+            assert p['blocks'] == 3 * (cin // 64) * (cout // 128) and p['qchunk'] >= B * H * (H + 1)
+        for H, cin, cout, v in ((26, 256, 512, 1), (52, 128, 256, 1), (104, 64, 128, 1), (208, 32, 64, 0)):
+            p = plan(B, H, cin, cout)
+            step = {0: 8 * 32, 1: 4 * 32}[v]
+            assert p['variant'] == v and p['direct'] == 0 and p['ranges'] >= 2, p
+            assert p['qchunk'] % step == 0 and p['qchunk'] >= 4 * step
+            assert (p['ranges'] - 1) * p['qchunk'] < B * H * (H + 1) <= p['ranges'] * p['qchunk']
+            cols = 3 * -(-cin // p['BC']) * -(-cout // p['BN'])
+            assert cols * p['ranges'] <= 256 and p['blocks'] >= cols * p['ranges']
+    assert plan(16, 416, 3, 32)['variant'] == -1                 # the image layer keeps its own kernel
+    assert plan(16, 1, 64, 64)['variant'] == -1                  # H = 1: no division constant for it
+    assert plan(64, 608, 32, 64)['variant'] == -1                # padded positions beyond the 24-bit multiplies

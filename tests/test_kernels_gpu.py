@@ -452,8 +452,16 @@ def test_conv_wgrad_single_range_overwrites(ops):
     assert_close(host(dW).reshape(k, k, Cin, Cout), ref, BF16_RTOL, 'wgrad single range, dirty dW')
 
 
+# bf16: the product rule (3x3: the row-of-taps kernel of conv_wgrad3.hip, else the per-tap kernel); bf16_gather: scalar reference gather;
+# bf16_pertap: the per-tap transpose-read kernel for every shape; bf16_row0..2: each variant of the row-of-taps kernel forced
+WGRAD_MODES = {'f32': 0, 'bf16': 0, 'bf16_gather': 1, 'bf16_pertap': 2, 'bf16_row0': 10, 'bf16_row1': 11, 'bf16_row2': 12}
+WGRAD_SHAPES += [(2, 13, 13, 96, 200, 3),     # ragged channel and filter tiles of every row-kernel variant
+                 (1, 16, 15, 64, 64, 3),      # W + 1 and H powers of two (the division constants' special case)
+                 (3, 9, 31, 40, 72, 3)]
+
+
 @pytest.mark.parametrize('shape', WGRAD_SHAPES)
-@pytest.mark.parametrize('mode', ['f32', 'bf16', 'bf16_gather'])
+@pytest.mark.parametrize('mode', list(WGRAD_MODES))
 def test_conv_wgrad(ops, shape, mode):
     B, H, W, Cin, Cout, k = shape
     tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
@@ -465,12 +473,17 @@ def test_conv_wgrad(ops, shape, mode):
     ref = R.conv2d_wgrad(x, dy, k, k)
     ldx, ldy = ops.pad8(Cin), ops.pad8(Cout)
     dW = torch.zeros(k * k * Cin * Cout, dtype=torch.float32, device='cuda')
-    ops.set_wgrad_variant(1 if mode == 'bf16_gather' else 0)
+    if mode.startswith('bf16_row') and (k != 3 or Cin <= 8):
+        pytest.skip('the row-of-taps kernel takes 3x3 layers beyond the image layer')
+    ops.set_wgrad_variant(WGRAD_MODES[mode])
     try:
         ops.conv2d_wgrad(dev(pad_channels(x, ldx), tdtype), dev(pad_channels(dy, ldy), tdtype), dW, B, H, W, Cin, ldx, Cout, ldy, k)
         torch.cuda.synchronize()
+        plan = ops.last_wgrad_plan()
     finally:
         ops.set_wgrad_variant(0)
+    if mode.startswith('bf16_row'):
+        assert plan['pair'] == 3, plan          # three taps per workgroup: the row kernel ran
     got = host(dW).reshape(k, k, Cin, Cout)
     # bf16 operands are exact products accumulated in f32: same tolerance class as f32
     assert_close(got, ref, F32_RTOL if mode == 'f32' else 1e-3, 'conv wgrad %s %s' % (shape, mode))

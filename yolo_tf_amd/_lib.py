@@ -114,6 +114,8 @@ QUERIES = {
     'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_set_pp': (_i, [_i, _i, _i, _i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
+    'yolo2_debug_wgrad_row_plan': (_i, [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
+    'yolo2_debug_magic_u32': (_i, [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),
     'yolo2_conv2d_workspace_bytes': (ctypes.c_size_t, [_i] * 7),
     'yolo2_bn_workspace_bytes': (ctypes.c_size_t, [_i]),
     'yolo2_bias_grad_workspace_bytes': (ctypes.c_size_t, [_i]),

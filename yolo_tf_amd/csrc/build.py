@@ -12,6 +12,7 @@ SOURCES = {
     'conv_igemm.hip': [],
     'conv_pp.hip': [],
     'conv_wgrad.hip': [],
+    'conv_wgrad3.hip': [],
     'conv_first.hip': [],
     'elementwise.hip': [],
     'head.hip': ['-ffp-contract=off'],

@@ -51,3 +51,10 @@ struct Y2BnBwd {
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
                          const Y2BnBwd &bz, int k_rotate, int grid, int sched, hipStream_t st);
+
+// conv_wgrad3.hip: 3x3 filter gradient with one kernel row of taps per workgroup over a padded pixel index (bf16).  variant < 0: the shape is not
+// taken (conv_wgrad.hip's per-tap kernel runs instead).
+struct Y2W3Plan { int variant, ks, qchunk, blocks, remap, direct, BC, BN, waves; };
+Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int force_variant);
+int y2_wgrad3_launch(const Y2W3Plan &p, const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t st);
+void y2_magic_u32(unsigned d, unsigned *m, unsigned *s);

@@ -31,11 +31,10 @@
 // layers, two taps per 64-row tile for <= 32 input channels (PAIR).  The per-DMA-piece border bookkeeping ((h, w) of every
 // staged pixel row, advanced branch-free by a constant pixel step) is the kernel's main non-MFMA cost.
 #include "common.h"
+#include "conv_shared.h"
 #include <atomic>
 #include <stdlib.h>
 #include <type_traits>
-
-#define Y2_OOB 0x80000000u
 
 // PAIR (BC = 64, Cin <= 32): the 64 tile rows hold TWO taps x 32 channels (rows 0-31: tap 2p, rows 32-63: tap 2p+1), so a
 // 32-channel layer (conv1: 25 GFLOP) does not spend half of every MFMA on zero rows.
@@ -367,13 +366,50 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_kernel(
     else write_tile(std::true_type{});
 }
 
-static std::atomic<int> g_wgrad_variant{0};      // tests only (scalar reference gather); process-wide by design
-extern "C" void yolo2_debug_set_wgrad_variant(int v) { g_wgrad_variant = v; }
+// tests / A-B only, process-wide by design: 0 = product rule; 1 = scalar reference gather (layout-proof, slow); 2 = the per-tap transpose-read
+// kernel of this file for every shape (round 4's product path); 10 + v = conv_wgrad3.hip's variant v (0..2) for every 3x3 bf16 shape it can take
+static std::atomic<int> g_wgrad_variant_raw{y2_env_int("YOLO2_WGRAD_VARIANT", 0)};
+static std::atomic<int> g_wgrad_variant{0};          // what this file's kernels see: 1 = scalar gather, else 0
+extern "C" void yolo2_debug_set_wgrad_variant(int v) {
+    g_wgrad_variant_raw = v;
+    g_wgrad_variant = (v == 1) ? 1 : 0;
+}
+static int wgrad_cus() {
+    static int cached_cus = 0;
+    if (!cached_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return cached_cus;
+}
+// the row-of-taps kernel (conv_wgrad3.hip) takes the bf16 3x3 layers beyond the image layer
+static Y2W3Plan wgrad_row_plan(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    Y2W3Plan none = {};
+    none.variant = -1;
+    const int raw = g_wgrad_variant_raw.load(std::memory_order_relaxed);
+    if (dtype != YOLO2_BF16 || ksize != 3 || raw == 1 || raw == 2) return none;
+    return y2_wgrad3_plan(B, H, W, Cin, Cout, wgrad_cus(), raw >= 10 ? raw - 10 : -1);
+}
 // plan of the calling thread's most recent launch: {BC, BNN, waves, PAIR, pixel ranges, XCD remap, blocks, direct store}
 static thread_local int g_last_wgrad_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" int yolo2_debug_last_wgrad_plan(int *out8) {
     if (!out8) return YOLO2_E_ARG;
     for (int i = 0; i < 8; ++i) out8[i] = g_last_wgrad_plan[i];
+    return YOLO2_OK;
+}
+
+// host-side planning of conv_wgrad3.hip, for tests without a GPU: out9 = {variant, ranges, padded pixels per range, blocks, remap, direct, BC, BN, waves}
+extern "C" int yolo2_debug_wgrad_row_plan(int B, int H, int W, int Cin, int Cout, int cus, int force_variant, int *out9) {
+    if (!out9) return YOLO2_E_ARG;
+    const Y2W3Plan p = y2_wgrad3_plan(B, H, W, Cin, Cout, cus, force_variant);
+    const int v[9] = {p.variant, p.ks, p.qchunk, p.blocks, p.remap, p.direct, p.BC, p.BN, p.waves};
+    for (int i = 0; i < 9; ++i) out9[i] = v[i];
+    return YOLO2_OK;
+}
+extern "C" int yolo2_debug_magic_u32(unsigned d, unsigned *m, unsigned *s) {
+    if (d < 2 || !m || !s) return YOLO2_E_ARG;
+    y2_magic_u32(d, m, s);
     return YOLO2_OK;
 }
 
@@ -475,6 +511,10 @@ extern "C" int yolo2_conv2d_wgrad_accumulates(int B, int H, int W, int Cin, int 
     static const bool first_direct = y2_env_int("YOLO2_FIRST_DIRECT", 1) != 0;
     if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize)) return 1;      // cross-workgroup atomics
     if (g_wgrad_variant != 0) return 1;
+    {
+        const Y2W3Plan rp = wgrad_row_plan(B, H, W, Cin, Cout, ksize, dtype);
+        if (rp.variant >= 0) return rp.direct ? 0 : 1;
+    }
     const int bkp = dtype == YOLO2_BF16 ? 32 : 16;
     const bool small = wgrad_small_tile(Cin, Cout, ksize);
     return wgrad_plan(B * H * W, Cin, Cout, ksize, small ? 64 : 128, small ? 64 : 128, bkp).ks == 1 ? 0 : 1;
@@ -500,6 +540,16 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
+    {
+        const Y2W3Plan rp = wgrad_row_plan(B, H, W, Cin, Cout, ksize, dtype);
+        if (rp.variant >= 0) {
+            const int plan[8] = {rp.BC, rp.BN, rp.waves, 3, rp.ks, rp.remap, rp.blocks, rp.direct};      // "pair" slot 3: three taps (a kernel row) per workgroup
+            for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = plan[i];
+            if (y2_wgrad3_launch(rp, X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, st) != 0) { yolo2_set_error("yolo2_conv2d_wgrad: no such row-kernel variant"); return YOLO2_E_ARG; }
+            Y2_CHECK_LAUNCH();
+            return YOLO2_OK;
+        }
+    }
     const bool small = wgrad_small_tile(Cin, Cout, ksize);
     if (small) {
         Y2_DISPATCH_DTYPE(dtype, launch_wgrad<T, 64, 64>(X, dY, dW, B, H, W, Cin, ldx, Cout, ldy, ksize, st));
@@ -509,10 +559,7 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
         // with two or three workgroups per CU the 32-pixel / 3-stage form wins (conv18: 66.5 vs 73.1 us).
         bool use64 = false;
         if (dtype == YOLO2_BF16 && g_wgrad_variant == 0) {
-            int dev = 0, cus = 256;
-            hipDeviceProp_t prop;
-            static int cached_cus = 0;
-            if (!cached_cus) cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : cus;
+            const int cached_cus = wgrad_cus();
             const WgradPlan pl = wgrad_plan(B * H * W, Cin, Cout, ksize, 128, 128, 32);
             use64 = pl.ks == 1 && 2 * pl.blocks <= 3 * cached_cus;
         }

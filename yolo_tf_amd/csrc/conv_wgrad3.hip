@@ -44,7 +44,11 @@ __device__ __forceinline__ unsigned y2_div_magic(unsigned q, unsigned m, unsigne
 
 // WC x WN waves tile the (channel, filter) extent of the workgroup: BC = 32 WC channels x BN = 64 WN filters x the three taps of kernel row dh;
 // KW groups of those take alternate P-pixel tiles of the workgroup's padded pixel range.  NSTAGE ring slots of KW sub-tiles each.
-template <int WC, int WN, int KW, int P, int NSTAGE>
+// ABL (timing ablations, -DY2W3_EXPERIMENTS builds only; results wrong by design): 1 = no MFMA, 2 = no fragment reads, 4 = no DMA inside the loop,
+// 8 = DMA pieces issued with a constant source offset (no address arithmetic), 16 = no barrier, 32 = no output stores, 64 = no wave-group reduction,
+// 128 = no prologue DMA either, 256 = the workgroup returns at once (launch cost of the geometry), 512 = s_memtime stamps at the phase boundaries of
+// every super-step; each wave leaves {kernel, wait + barrier, DMA issue, reads + MFMA issue, table build, prologue, epilogue} cycle sums in dW (scripts/w3_phase_cycles.py)
+template <int WC, int WN, int KW, int P, int NSTAGE, int ABL = 0>
 __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
     const bf16 *__restrict__ X, unsigned x_bytes, const bf16 *__restrict__ dY, unsigned y_bytes, float *__restrict__ dW, int H, int W, int Cin, int ldx,
     int Cout, int ldy, int Mp, int CT, int NT, int qchunk, int KS, int remap, int direct, unsigned mW, unsigned sW, unsigned mH, unsigned sH) {
@@ -68,13 +72,24 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
     static_assert(XH >= 1 && XR % XRPI == 0 && P % YRPI == 0 && P % 16 == 0, "tile geometry");
     static_assert(4 % (XRPL * XSWM) == 0 && 4 % (YRPL * YSWM) == 0, "the swizzle period (in pixel rows) divides the 4-row read step");
     static_assert(XRPI % 4 == 0 && YRPI % 4 == 0, "a lane's swizzle term is the same in every piece");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4 && NSTAGE * STAGE <= 160 * 1024, "LDS ring");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "LDS ring");
     static_assert(KW == 1 || (KW / 2) * WC * WN * 6 * 4096 <= NSTAGE * STAGE, "the accumulator images of the wave-group reduction fit the ring");
 
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE];
+    // Source-offset table (DMA address generation): one u32 per staged ROW of a stage -- KW * XR X rows, then KW * P dY rows, then one
+    // permanently-out-of-range slot -- double-buffered by stage parity.  Each row's offset is computed ONCE (one thread per row, after the MFMA
+    // phase, two stages ahead of its use) instead of once per 16-byte chunk of the row by every lane of every DMA piece: the 64 lanes of a
+    // piece cover only 4-16 rows, and that 8-fold redundant arithmetic was 5 VALU + 2.4 SALU per MFMA (profiles/r05_w3_sq_counters_v1.md).
+    constexpr int NTHR = NWAVE * 64;
+    constexpr int NENT_X = KW * XR, NENT = NENT_X + KW * P;          // table entries per stage
+    constexpr int NEPT = (NENT + 1 + NTHR - 1) / NTHR;               // entries a thread computes per stage (the out-of-range slot included)
+    constexpr int TBLB = ((NENT + 1) * 4 + 15) / 16 * 16;            // bytes per parity
+    static_assert(NSTAGE * STAGE + 2 * TBLB <= 160 * 1024, "LDS: ring + offset tables");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE + 2 * TBLB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long tm_start = 0;
+    if constexpr (ABL & 512) tm_start = __builtin_amdgcn_s_memtime();
     const int kw = wave / (WC * WN), wcn = wave % (WC * WN), wc = wcn / WN, wn = wcn % WN;
 
     // ---- block -> (kernel row, channel tile, filter tile, pixel range).  Workgroups of one pixel range read the same X / dY rows: with >= 8
@@ -95,6 +110,7 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
         by = blockIdx.x / ncols;
     }
     if (by >= KS) return;
+    if constexpr (ABL & 256) { if (dW[0] == 123.456f) dW[1] = (float)col; return; }
     const int dh = col % 3 - 1;
     const int nt = (col / 3) % NT, ct = col / (3 * NT);
     const int c0 = ct * BC, n0 = nt * BN;
@@ -106,33 +122,79 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(X), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(dY), 0, y_bytes, 0x00020000);
 
-    // ---- per-lane DMA constants: row inside a piece, source channel chunk (swizzled), permanently-out-of-range flag folded into the offset
+    // ---- per-lane DMA constants: row inside a piece, source channel chunk (swizzled)
     const int xrow_l = lane / XCH, yrow_l = lane / YCH;
-    unsigned x_cb, y_cb;
-    {
-        const int xc = c0 + (((lane % XCH) ^ (((xrow_l / XRPL) % XSWM) * 4)) * 8);
-        x_cb = (xc < Cin && xc < ldx) ? (unsigned)xc * 2u : Y2_OOB;       // (offset + 2^31 stays beyond every operand: they are < 2^31 bytes)
-        const int yc = n0 + (((lane % YCH) ^ (((yrow_l / YRPL) % YSWM) * 4)) * 8);
-        y_cb = (yc < Cout && yc < ldy) ? (unsigned)yc * 2u : Y2_OOB;
-    }
+    const int xc = c0 + (((lane % XCH) ^ (((xrow_l / XRPL) % XSWM) * 4)) * 8);
+    const int yc = n0 + (((lane % YCH) ^ (((yrow_l / YRPL) % YSWM) * 4)) * 8);
+    const bool xc_ok = xc < Cin && xc < ldx, yc_ok = yc < Cout && yc < ldy;
+    const unsigned x_cb = xc_ok ? (unsigned)xc * 2u : 0u, y_cb = yc_ok ? (unsigned)yc * 2u : 0u;
     const unsigned W1 = (unsigned)(W + 1), ldx2 = (unsigned)ldx * 2u, ldy2 = (unsigned)ldy * 2u;
     const int dhW = dh * W;
+    const unsigned smem_base = y2_lds_addr(smem);
+    const unsigned tbl_base = smem_base + (unsigned)(NSTAGE * STAGE);
+    // table read address of this lane per DMA piece (parity 0; parity 1 = + TBLB through the instruction's offset field): the row's entry, or
+    // the out-of-range slot for lanes whose channel chunk lies beyond the tensor
+    unsigned tx[XJ], ty[YJ];
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int p = wave + j * NWAVE, sub = p / XP, pp = p - sub * XP;
+        tx[j] = tbl_base + 4u * (unsigned)((xc_ok && p < NXP) ? sub * XR + pp * XRPI + xrow_l : NENT);
+    }
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+        const int p = wave + j * NWAVE, sub = p / YP, pp = p - sub * YP;
+        ty[j] = tbl_base + 4u * (unsigned)((yc_ok && p < NYP) ? NENT_X + sub * P + pp * YRPI + yrow_l : NENT);
+    }
+    // the entries this thread computes per stage: position offset of the row relative to the stage's first padded position
+    int ent_off[NEPT];
+    unsigned ent_addr[NEPT];
+#pragma unroll
+    for (int k = 0; k < NEPT; ++k) {
+        const int e = tid + k * NTHR;
+        ent_off[k] = e < NENT_X ? (e / XR) * P - XH + e % XR : e - NENT_X;        // (dY rows: sub * P + i = e - NENT_X)
+        ent_addr[k] = tbl_base + 4u * (unsigned)(e < NENT ? e : NENT);          // (threads beyond the table rewrite the out-of-range slot)
+    }
+    // writes the table of stage t (parity t & 1).  Stateless: (image row, column) of a padded position by two multiply-high divisions.
+    auto build_table = [&](int t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int qs = qb + t * (KW * P);
+        const unsigned par = (t & 1) ? (unsigned)TBLB : 0u;
+#pragma unroll
+        for (int k = 0; k < NEPT; ++k) {
+            const int e = tid + k * NTHR;
+            const unsigned q = (unsigned)(qs + ent_off[k]);           // wraps below 0: fails the range test
+            const unsigned R = y2_div_magic(q, mW, sW);               // image row counted over the whole batch
+            const unsigned c = q - __umul24(R, W1);                   // column; W = the zero column
+            const unsigned r = R - __umul24(y2_div_magic(R, mH, sH), (unsigned)H);
+            const bool isx = e < NENT_X;
+            // X rows: the pixel dh image rows away (zero outside the image); dY rows: the pixel itself, zero beyond this block's range
+            const bool ok = (c < (unsigned)W) & (isx ? (q < (unsigned)Mp) & ((unsigned)((int)r + dh) < (unsigned)H) : (q < (unsigned)qe)) & (e < NENT);
+            const unsigned src = isx ? __umul24((unsigned)((int)(q - R) + dhW), ldx2) : __umul24(q - R, ldy2);
+            const unsigned v = ok ? src : Y2_OOB;
+            asm volatile("ds_write_b32 %0, %1" ::"v"(ent_addr[k] + par), "v"(v) : "memory");
+        }
+#endif
+    };
 
     int t_issue = 0, i_slot = 0;
-    auto issue_stage = [&]() {
+    // DMA pieces of stage t_issue: every lane reads its row's source offset from the table (inline asm: a compiler-visible LDS read would be
+    // preceded by vmcnt(0) while DMA is in flight, common.h), adds its channel chunk and issues the 1 KiB piece
+    auto issue_stage = [&](auto par_) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        constexpr int PAR = decltype(par_)::value * TBLB;
         unsigned char *base = smem + i_slot * STAGE;
-        const int qs = qb + t_issue * (KW * P);
+        unsigned ex[XJ], ey[YJ];
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ex[j]) : "v"(tx[j]), "n"(PAR) : "memory");
+#pragma unroll
+        for (int j = 0; j < YJ; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ey[j]) : "v"(ty[j]), "n"(PAR) : "memory");
 #pragma unroll
         for (int j = 0; j < XJ; ++j) {
             const int p = wave + j * NWAVE;                           // wave-uniform
             if (p < NXP) {
                 const int sub = p / XP, pp = p - sub * XP;
-                const unsigned q = (unsigned)(qs + sub * P - XH + pp * XRPI + xrow_l);      // padded position of this lane's row (wraps below 0: fails the range test)
-                const unsigned R = y2_div_magic(q, mW, sW);           // image row counted over the whole batch
-                const unsigned c = q - __umul24(R, W1);               // column, W = the zero column
-                const unsigned r = R - __umul24(y2_div_magic(R, mH, sH), (unsigned)H);
-                const bool ok = q < (unsigned)Mp && c < (unsigned)W && (unsigned)((int)r + dh) < (unsigned)H;
-                const unsigned voff = ok ? __umul24((unsigned)((int)(q - R) + dhW), ldx2) + x_cb : Y2_OOB;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ex[j]) : "n"(XJ + YJ - 1 - j) : "memory");
+                const unsigned voff = (ABL & 8) ? x_cb + (unsigned)lane * 16u : ex[j] + x_cb;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (__attribute__((address_space(3))) void *)(base + sub * SUB + pp * 1024), 16, voff, 0, 0, 0);
             }
         }
@@ -141,20 +203,28 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
             const int p = wave + j * NWAVE;
             if (p < NYP) {
                 const int sub = p / YP, pp = p - sub * YP;
-                const unsigned q = (unsigned)(qs + sub * P + pp * YRPI + yrow_l);
-                const unsigned R = y2_div_magic(q, mW, sW);
-                const unsigned c = q - __umul24(R, W1);
-                const bool ok = q < (unsigned)qe && c < (unsigned)W;                       // (rows beyond this block's range contribute nothing)
-                const unsigned voff = ok ? __umul24(q - R, ldy2) + y_cb : Y2_OOB;
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ey[j]) : "n"(YJ - 1 - j) : "memory");
+                const unsigned voff = (ABL & 8) ? y_cb + (unsigned)lane * 16u : ey[j] + y_cb;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcY, (__attribute__((address_space(3))) void *)(base + sub * SUB + XT + pp * 1024), 16, voff, 0, 0, 0);
             }
         }
+#endif
         ++t_issue;
         i_slot = (i_slot + 1 == NSTAGE) ? 0 : i_slot + 1;
     };
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (t_issue < nsuper) issue_stage();
+    // prologue: tables of the first NSTAGE stages, NSTAGE - 1 stages in flight
+    if constexpr (!(ABL & 128)) {
+        y2_static_for<0, NSTAGE - 1>([&](auto t_) {
+            constexpr int t = decltype(t_)::value;
+            if (t < nsuper) {
+                build_table(t);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                issue_stage(std::integral_constant<int, t & 1>{});
+            }
+        });
+        if (NSTAGE - 1 < nsuper) build_table(NSTAGE - 1);     // read by iteration 0, behind its barrier
+    }
 
     f32x16 acc[3][2];
 #pragma unroll
@@ -179,16 +249,23 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
         const int ch = (wn * 2 + j) * 32 + co;
         ya[j] = (unsigned)(kw * SUB + XT + px * YROWB + (((ch >> 3) ^ (((px / YRPL) % YSWM) * 4)) << 4) + ((ch & 7) << 1));
     }
-    const unsigned smem_base = y2_lds_addr(smem);
 
+    unsigned long long tm_k0 = tm_start, tm_pro = 0, tm_a = 0, tm_b = 0, tm_c = 0, tm_d = 0, tm_wait = 0, tm_issue = 0, tm_mfma = 0, tm_tbl = 0;
+    if constexpr (ABL & 512) tm_pro = __builtin_amdgcn_s_memtime();
     int c_slot = 0;
-    for (int s = 0; s < nsuper; ++s) {
+    // one super-step: stage s has landed (counted vmcnt) and the table of stage s + NSTAGE - 1 is written (lgkmcnt) -> barrier -> that stage's DMA
+    // pieces -> the tile's MFMA steps -> the table of the stage after it.  SP = s & 1 (the table parities are compile-time offsets).
+    auto super_step = [&](int s, auto sp_) {
+        constexpr int SP = decltype(sp_)::value;
+        if constexpr (ABL & 512) { tm_a = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
         const int ahead = min(NSTAGE - 2, t_issue - 1 - s);           // stages issued behind the one consumed now
-        if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_MIN) : "memory");
-        else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_MIN) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t_issue < nsuper) issue_stage();
+        if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PIECES_MIN) : "memory");
+        else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES_MIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+        if constexpr (ABL & 512) { tm_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (!(ABL & 4) && t_issue < nsuper) issue_stage(std::integral_constant<int, (SP + NSTAGE - 1) & 1>{});
+        if constexpr (ABL & 512) { tm_c = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #if defined(__HIP_DEVICE_COMPILE__)
         const unsigned sb = smem_base + (unsigned)(c_slot * STAGE);
         c_slot = (c_slot + 1 == NSTAGE) ? 0 : c_slot + 1;
@@ -200,6 +277,13 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
         u32x2 fa[2][3][2], fb[2][2][2];
         auto load = [&](auto ks_) {
             constexpr int ks = decltype(ks_)::value, bf = ks & 1;
+            if constexpr (ABL & 2) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { fa[bf][d][0] = u32x2{xs[d], 0u}; fa[bf][d][1] = u32x2{0u, xs[d]}; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { fb[bf][j][0] = u32x2{ys[j], 0u}; fb[bf][j][1] = u32x2{0u, ys[j]}; }
+                return;
+            }
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 fa[bf][d][0] = y2_tr16_read_off<(16 * ks) * XROWB>(xs[d]);
@@ -220,6 +304,13 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
             } else {
                 y2_lgkm_wait10<0>(fa[bf][0][0], fa[bf][0][1], fa[bf][1][0], fa[bf][1][1], fa[bf][2][0], fa[bf][2][1], fb[bf][0][0], fb[bf][0][1], fb[bf][1][0], fb[bf][1][1]);
             }
+            if constexpr (ABL & 1) {       // keep the fragments alive without the matrix pipe
+#pragma unroll
+                for (int d = 0; d < 3; ++d)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[d][j][0] += __builtin_bit_cast(float, fa[bf][d][0][0] ^ fa[bf][d][1][1] ^ fb[bf][j][0][0] ^ fb[bf][j][1][1]);
+                return;
+            }
 #pragma unroll
             for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -227,11 +318,24 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
                     acc[d][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y2_frag16(fa[bf][d][0], fa[bf][d][1]), y2_frag16(fb[bf][j][0], fb[bf][j][1]), acc[d][j], 0, 0, 0);
         });
 #endif
+        if constexpr (ABL & 512) { __builtin_amdgcn_sched_barrier(0); tm_d = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        if (!(ABL & 4) && s + NSTAGE < nsuper) build_table(s + NSTAGE);
+        if constexpr (ABL & 512) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long tm_e = __builtin_amdgcn_s_memtime();
+            tm_wait += tm_b - tm_a; tm_issue += tm_c - tm_b; tm_mfma += tm_d - tm_c; tm_tbl += tm_e - tm_d;
+        }
+    };
+    for (int s = 0; s < nsuper; s += 2) {
+        super_step(s, std::integral_constant<int, 0>{});
+        if (s + 1 < nsuper) super_step(s + 1, std::integral_constant<int, 1>{});
     }
 
+    unsigned long long tm_epi = 0;
+    if constexpr (ABL & 512) tm_epi = __builtin_amdgcn_s_memtime();
     // ---- the KW wave groups hold partial sums over disjoint pixel tiles: tree reduction through LDS (the ring is free: every DMA has landed
     // and been read), group 0 ends with the workgroup's sums
-    if constexpr (KW > 1) {
+    if constexpr (KW > 1 && !(ABL & 64)) {
         __syncthreads();
         f32x4 *img = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
@@ -292,6 +396,22 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
             }
         }
     };
+    if constexpr ((ABL & 512) != 0) {
+        // (stamped build: the real stores, then the sums behind them -- the caller allocates blocks * waves * 8 extra floats pairs at the end of dW)
+        if (c0 + BC <= Cin && n0 + BN <= Cout) write_tile(std::false_type{});
+        else write_tile(std::true_type{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tm_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(dW + (long)9 * Cin * Cout) + ((long)blockIdx.x * NWAVE + wave) * 8;
+            dbg[0] = tm_end - tm_k0; dbg[1] = tm_wait; dbg[2] = tm_issue; dbg[3] = tm_mfma; dbg[4] = tm_tbl; dbg[5] = tm_pro - tm_k0; dbg[6] = tm_end - tm_epi; dbg[7] = (unsigned long long)nsuper;
+        }
+        return;
+    }
+    if constexpr (ABL & 32) {
+        if (acc[0][0][0] == 123.456f && acc[2][1][5] == 1.0f) dW[0] = acc[1][1][3];       // (keeps the accumulators alive, stores nothing)
+        return;
+    }
     if (c0 + BC <= Cin && n0 + BN <= Cout) write_tile(std::false_type{});
     else write_tile(std::true_type{});
 }
@@ -310,7 +430,7 @@ void y2_magic_u32(unsigned d, unsigned *m, unsigned *s) {
 // four wave groups (split reductions: the atomics per launch are workgroups x 12 K elements); 2 = 64 x 128 tile, two wave groups (single-range
 // grids: 13x13 stages, plain stores).
 struct Y2W3Geom { int BC, BN, KW, P, waves; };
-static const Y2W3Geom g_w3_geom[3] = {{32, 64, 8, 32, 8}, {64, 64, 4, 32, 8}, {64, 128, 2, 64, 8}};
+static const Y2W3Geom g_w3_geom[5] = {{32, 64, 8, 32, 8}, {64, 64, 4, 32, 8}, {64, 128, 2, 64, 8}, {64, 128, 1, 64, 4}, {128, 128, 1, 64, 8}};
 
 Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int force_variant) {
     Y2W3Plan p = {};
@@ -320,7 +440,7 @@ Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int for
     if (cus <= 0) cus = 256;
     auto cols = [&](int v) { return 3L * cdiv(Cin, g_w3_geom[v].BC) * cdiv(Cout, g_w3_geom[v].BN); };
     int v;
-    if (force_variant >= 0 && force_variant <= 2) v = force_variant;
+    if (force_variant >= 0 && force_variant <= 4) v = force_variant;
     else if (Cin <= 32) v = 0;
     else if (cols(2) * 10 >= (long)cus * 6) v = 2;                             // the 64 x 128 tile grid alone gives >= 60 % of the CUs a workgroup
     else v = 1;
@@ -330,7 +450,7 @@ Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int for
     long ks = ncols >= cus ? 1 : cus / ncols;
     const long max_ks = Mp / (4L * step) > 1 ? Mp / (4L * step) : 1;          // >= four ring turns per workgroup
     if (ks > max_ks) ks = max_ks;
-    if (v == 2 && force_variant < 0) ks = 1;
+    if (v >= 2 && force_variant < 0) ks = 1;
     p.qchunk = cdiv(cdiv(Mp, ks), step) * step;
     p.ks = cdiv(Mp, p.qchunk);
     p.variant = v;
@@ -351,10 +471,41 @@ int y2_wgrad3_launch(const Y2W3Plan &p, const void *X, const void *dY, float *dW
 #define Y2W3_LAUNCH(WCv, WNv, KWv, Pv, NSv)                                                                                                         \
     conv_wgrad_row_kernel<WCv, WNv, KWv, Pv, NSv><<<dim3(p.blocks), WCv * WNv * KWv * 64, 0, st>>>((const bf16 *)X, x_bytes, (const bf16 *)dY, y_bytes, dW, H, W, Cin, \
                                                                                                    ldx, Cout, ldy, Mp, CT, NT, p.qchunk, p.ks, p.remap, p.direct, mW, sW, mH, sH)
+#ifdef Y2W3_EXPERIMENTS
+    static const int abl = y2_env_int("YOLO2_W3_ABL", 0);
+#define Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, Av)                                                                                                        \
+    conv_wgrad_row_kernel<WCv, WNv, KWv, Pv, NSv, Av><<<dim3(p.blocks), WCv * WNv * KWv * 64, 0, st>>>((const bf16 *)X, x_bytes, (const bf16 *)dY, y_bytes, dW, H, W, \
+                                                                                                       Cin, ldx, Cout, ldy, Mp, CT, NT, p.qchunk, p.ks, p.remap, p.direct, mW, sW, mH, sH)
+#define Y2W3_ABL_CASES(WCv, WNv, KWv, Pv, NSv)                                                                          \
+    switch (abl) {                                                                                                      \
+        case 1: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 1); return 0;                                                          \
+        case 2: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 2); return 0;                                                          \
+        case 3: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 3); return 0;                                                          \
+        case 4: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 4); return 0;                                                          \
+        case 7: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 7); return 0;                                                          \
+        case 8: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 8); return 0;                                                          \
+        case 16: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 16); return 0;                                                        \
+        case 6: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 6); return 0;                                                          \
+        case 5: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 5); return 0;                                                          \
+        case 39: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 39); return 0;                                                        \
+        case 231: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 231); return 0;                                                      \
+        case 256: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 256); return 0;                                                      \
+        case 512: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 512); return 0;                                                      \
+        case 103: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 103); return 0;                                                      \
+        case 32: Y2W3_ABL(WCv, WNv, KWv, Pv, NSv, 32); return 0;                                                        \
+        default: break;                                                                                                 \
+    }
+    if (abl && p.variant == 2) { Y2W3_ABL_CASES(2, 2, 2, 64, 3) }
+    if (abl && p.variant == 1) { Y2W3_ABL_CASES(2, 1, 4, 32, 4) }
+    if (abl == 512 && p.variant == 3) { Y2W3_ABL(2, 2, 1, 64, 3, 512); return 0; }
+    if (abl == 512 && p.variant == 4) { Y2W3_ABL(4, 2, 1, 64, 3, 512); return 0; }
+#endif
     switch (p.variant) {
         case 0: Y2W3_LAUNCH(1, 1, 8, 32, 2); break;
         case 1: Y2W3_LAUNCH(2, 1, 4, 32, 4); break;
         case 2: Y2W3_LAUNCH(2, 2, 2, 64, 3); break;
+        case 3: Y2W3_LAUNCH(2, 2, 1, 64, 3); break;
+        case 4: Y2W3_LAUNCH(4, 2, 1, 64, 3); break;
         default: return 1;
     }
 #undef Y2W3_LAUNCH
