@@ -12,7 +12,7 @@ B = int(os.environ.get('B', 16))
 if os.environ.get('LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['LAYERS'].split(',')]
 VARIANTS = [int(v) for v in os.environ.get('VARIANTS', '2,0,10,11,12').split(',')]
-NAMES = {2: 'per-tap', 0: 'rule', 10: 'row v0', 11: 'row v1', 12: 'row v2', 13: 'row v3', 14: 'row v4'}
+NAMES = {2: 'per-tap', 0: 'rule', 10: 'row v0', 11: 'row v1', 12: 'row v2', 13: 'row v3', 14: 'row v4', 15: 'row v5'}
 T = torch.bfloat16
 tag = sys.argv[1] if len(sys.argv) > 1 else ''
 

@@ -258,25 +258,30 @@ def test_padded_pixel_index_decomposition_equals_the_filter_gradient(q, B, H, W,
 
 def test_row_kernel_plans(q):
     """Variant and pixel-range rule of the row-of-taps kernel on a 256-CU device: 13x13 stages store (one range, plain stores, L2-stationary
-    order), the split layers keep one workgroup per CU at most, every range is whole ring turns, ranges cover the padded pixels."""
+    order), the split layers keep one workgroup per CU at most with ranges in multiples of 8 (one XCD per range), every range is whole ring
+    turns, ranges cover the padded pixels; narrow layers stay on the per-tap kernel."""
     import ctypes
     def plan(B, H, cin, cout, cus=256, force=-1):
         out = (ctypes.c_int * 9)()
         assert q('yolo2_debug_wgrad_row_plan', B, H, H, cin, cout, cus, force, out) == 0
         return dict(zip(('variant', 'ranges', 'qchunk', 'blocks', 'remap', 'direct', 'BC', 'BN', 'waves'), list(out)))
     for B in (4, 8, 16, 32):
-        for H, cin, cout in ((13, 512, 1024), (13, 1024, 1024), (13, 3072, 1024)):
+        for H, cin, cout, v in ((13, 512, 1024, 2), (13, 1024, 1024, 4), (13, 3072, 1024, 2)):
             p = plan(B, H, cin, cout)
-            assert (p['variant'], p['ranges'], p['direct'], p['remap'], p['BC'], p['BN']) == (2, 1, 1, 2, 64, 128), p
-            assert p['blocks'] == 3 * (cin // 64) * (cout // 128) and p['qchunk'] >= B * H * (H + 1)
-        for H, cin, cout, v in ((26, 256, 512, 1), (52, 128, 256, 1), (104, 64, 128, 1), (208, 32, 64, 0)):
+            assert (p['variant'], p['ranges'], p['direct'], p['remap']) == (v, 1, 1, 2), p
+            assert p['blocks'] == 3 * (cin // p['BC']) * (cout // p['BN']) and p['qchunk'] >= B * H * (H + 1)
+        for H, cin, cout in ((26, 256, 512), (52, 128, 256), (104, 64, 128)):
             p = plan(B, H, cin, cout)
-            step = {0: 8 * 32, 1: 4 * 32}[v]
-            assert p['variant'] == v and p['direct'] == 0 and p['ranges'] >= 2, p
+            step = 4 * 64
+            assert (p['variant'], p['direct'], p['BC'], p['BN']) == (5, 0, 64, 64) and p['ranges'] >= 2, p
             assert p['qchunk'] % step == 0 and p['qchunk'] >= 4 * step
             assert (p['ranges'] - 1) * p['qchunk'] < B * H * (H + 1) <= p['ranges'] * p['qchunk']
             cols = 3 * -(-cin // p['BC']) * -(-cout // p['BN'])
             assert cols * p['ranges'] <= 256 and p['blocks'] >= cols * p['ranges']
+            assert p['remap'] == (1 if p['ranges'] >= 8 else 0)
+        assert plan(B, 208, 32, 64)['variant'] == -1             # <= 32 input channels: the per-tap kernel's tap-pair form
+    assert plan(16, 52, 128, 256)['ranges'] == 8                 # 256 / 24 = 10 -> 8: one range per XCD
     assert plan(16, 416, 3, 32)['variant'] == -1                 # the image layer keeps its own kernel
     assert plan(16, 1, 64, 64)['variant'] == -1                  # H = 1: no division constant for it
-    assert plan(64, 608, 32, 64)['variant'] == -1                # padded positions beyond the 24-bit multiplies
+    assert plan(64, 608, 64, 64)['variant'] == -1                # padded positions beyond the 24-bit multiplies
+    assert plan(16, 13, 512, 1024, force=0)['variant'] == -1     # experiment variants are not in the product build

@@ -453,8 +453,8 @@ def test_conv_wgrad_single_range_overwrites(ops):
 
 
 # bf16: the product rule (3x3: the row-of-taps kernel of conv_wgrad3.hip, else the per-tap kernel); bf16_gather: scalar reference gather;
-# bf16_pertap: the per-tap transpose-read kernel for every shape; bf16_row0..2: each variant of the row-of-taps kernel forced
-WGRAD_MODES = {'f32': 0, 'bf16': 0, 'bf16_gather': 1, 'bf16_pertap': 2, 'bf16_row0': 10, 'bf16_row1': 11, 'bf16_row2': 12}
+# bf16_pertap: the per-tap transpose-read kernel for every shape; bf16_row2 / 4 / 5: each product variant of the row-of-taps kernel forced
+WGRAD_MODES = {'f32': 0, 'bf16': 0, 'bf16_gather': 1, 'bf16_pertap': 2, 'bf16_row2': 12, 'bf16_row4': 14, 'bf16_row5': 15}
 WGRAD_SHAPES += [(2, 13, 13, 96, 200, 3),     # ragged channel and filter tiles of every row-kernel variant
                  (1, 16, 15, 64, 64, 3),      # W + 1 and H powers of two (the division constants' special case)
                  (3, 9, 31, 40, 72, 3)]
