@@ -129,7 +129,9 @@ int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int to
  * of the updated filters, in one pass: equal, bit for bit, to yolo2_adam on the same elements followed by yolo2_filter_prep_batch.
  * descs[i].W must point into `params`; grads / m / v are arenas with the same element layout.  small_ranges_device: n_small pairs
  * (element offset, count) of the parameters that are not filters (gamma, beta, biases), updated by the same launch.  alpha is the
- * bias-corrected step size (lr * sqrt(1 - beta2^t) / (1 - beta1^t)), gscale multiplies the gradient (1 / world size). */
+ * bias-corrected step size (lr * sqrt(1 - beta2^t) / (1 - beta1^t)), gscale multiplies the gradient (1 / world size).  A table may hold ONE
+ * layer (first_block 0: a layer updated as soon as its gradient is final, while backward continues on another stream) or none (n = 0,
+ * total_blocks = 0: only the small ranges). */
 int yolo2_adam_filter_prep(const yolo2_filter_desc *descs_device, int n, int total_blocks, const long *small_ranges_device, int n_small,
                            float *params, const float *grads, float *m, float *v, float alpha, float beta1, float beta2, float eps,
                            float gscale, int dtype, void *stream);

@@ -241,6 +241,48 @@ def test_full_size_training_properties(basedir):
     assert torch.isfinite(e.params).all() and torch.isfinite(e.grads).all()
 
 
+def test_layerwise_adam_equals_the_single_launch_bit_for_bit(basedir, monkeypatch):
+    """With YOLO2_EARLY_ADAM=1 TrainSession.step updates each layer's filter as soon as its gradient is final (engine.adam_update_layer on a
+    third stream, then adam_update_small; off by default: measured slower, profiles/r05_early_adam.txt): on the SAME gradients the parameters, both Adam slots and both MFMA operand layouts of every layer must equal the
+    one-launch form (adam_update_and_prepare) bit for bit -- and a session stepping that way must train (finite, decreasing loss)."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    B = 4
+    monkeypatch.setenv('YOLO2_EARLY_ADAM', '1')
+    b, _ = make_builder('darknet', 20, 160, True, basedir)
+    sess = TrainSession(b, B, dtype='bf16', optimizer='adam', learning_rate=1e-3, seed=2)
+    assert sess.early_adam
+    e, opt = sess.engine, sess.optimizer
+    g = torch.Generator(device='cuda').manual_seed(7)
+    images = torch.rand(B, 160, 160, 3, device='cuda', generator=g) * 255
+    sess.upload_labels(data.synthetic_batch(B, 20, 5, 5, seed=8))
+    sess.forward_backward(images)                      # gradients only: no update (defer_collectives = False)
+    torch.cuda.synchronize()
+    p0, m0, v0 = e.params.clone(), opt.slots[0].clone(), opt.slots[1].clone()
+    convs = [op for op in e.graph.ops if op['kind'] == 'conv']
+    operands = lambda: [t.clone() for op in convs for t in (e.conv[op['name']]['Ffwd'], e.conv[op['name']].get('Fdgr')) if t is not None]
+    args = (3e-4, 0.9, 0.999, 1e-8, 1.0)
+    e.adam_update_and_prepare(opt.slots[0], opt.slots[1], *args)
+    torch.cuda.synchronize()
+    ref = (e.params.clone(), opt.slots[0].clone(), opt.slots[1].clone(), operands())
+    e.params.copy_(p0); opt.slots[0].copy_(m0); opt.slots[1].copy_(v0)
+    for op in reversed(convs):                         # backward order, as the step issues them
+        e.adam_update_layer(op, opt.slots[0], opt.slots[1], *args)
+    e.adam_update_small(opt.slots[0], opt.slots[1], *args)
+    torch.cuda.synchronize()
+    got = (e.params, opt.slots[0], opt.slots[1], operands())
+    for a, r in zip(got[:3], ref[:3]):
+        assert torch.equal(a, r)
+    assert not torch.equal(e.params, p0)
+    for a, r in zip(got[3], ref[3]):
+        assert torch.equal(a, r)
+    losses = []
+    for _ in range(5):
+        sess.step(images)
+        losses.append(sess.fetch()['total_loss'])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
 def _nms_c_oracle(conf, mn, mx, thr, thr_iou):
     """oracle/nms_ref.c on one image; returns (conf after, order)."""
     lib = ctypes.CDLL(os.path.join(ROOT, 'oracle', 'libnms_ref.so'))

@@ -2150,7 +2150,9 @@ __global__ __launch_bounds__(256) void adam_filter_prep_kernel(const yolo2_filte
 extern "C" int yolo2_adam_filter_prep(const yolo2_filter_desc *descs_device, int n, int total_blocks, const long *small_ranges_device, int n_small,
                                       float *params, const float *grads, float *m, float *v, float alpha, float beta1, float beta2, float eps,
                                       float gscale, int dtype, void *stream) {
-    Y2_CHECK_ARG(descs_device && n > 0 && total_blocks > 0 && n_small >= 0 && (small_ranges_device || n_small == 0) && params && grads && m && v);
+    // (n == 0: only the non-filter ranges -- the last launch of a step whose filters were updated layer by layer during backward)
+    Y2_CHECK_ARG(n >= 0 && total_blocks >= 0 && (n > 0) == (total_blocks > 0) && (descs_device || n == 0) && n_small >= 0 && total_blocks + n_small > 0 &&
+                 (small_ranges_device || n_small == 0) && params && grads && m && v);
     Y2_CHECK_ARG(((((uintptr_t)params) | ((uintptr_t)grads) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0);
     const Y2AdamArgs a{params, grads, m, v, alpha, 1.0f - beta1, 1.0f - beta2, eps, gscale};
     Y2_DISPATCH_DTYPE(dtype, adam_filter_prep_kernel<T><<<total_blocks + n_small, 256, 0, (hipStream_t)stream>>>(descs_device, n, total_blocks, small_ranges_device, a));

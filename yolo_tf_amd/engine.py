@@ -428,6 +428,15 @@ class Engine(object):
         raw = bytes(arr)
         self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._fdesc_n, self._fdesc_blocks = len(convs), first
+        # the same descriptors as one-layer tables (first_block = 0 each): the per-layer optimizer launches of adam_update_layer
+        import ctypes
+        self._fdesc1_info = {}
+        size = ctypes.sizeof(FilterDesc)
+        bounds = [d.first_block for d in arr] + [first]
+        for i, (d, op) in enumerate(zip(arr, convs)):
+            self._fdesc1_info[op['name']] = (i * size, bounds[i + 1] - bounds[i])
+            d.first_block = 0
+        self._fdesc1 = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         covered = sorted(self.param_offsets[op['weights'].name] for op in self.graph.ops if op['kind'] == 'conv')
         small = sorted(v for k, v in self.param_offsets.items() if v not in covered)
         flat = [x for o, n in small for x in (o, n)]
@@ -440,6 +449,20 @@ class Engine(object):
         self._filter_descs()
         ops.adam_filter_prep(self._fdesc, self._fdesc_n, self._fdesc_blocks, self._small, self._n_small, self.params, self.grads, m, v,
                              alpha, beta1, beta2, eps, gscale, self.dtype)
+        self._filters_dirty = False
+
+    def adam_update_layer(self, op, m, v, alpha, beta1, beta2, eps, gscale):
+        """Adam + both operand layouts of ONE layer's filter, on the current stream (the same kernel as adam_update_and_prepare over a
+        one-entry descriptor table: bit-identical).  The caller orders it behind the layer's filter gradient AND its data gradient -- the
+        launch rewrites the data-gradient operand Fdgr -- and finishes the step with adam_update_small."""
+        self._filter_descs()
+        off, blocks = self._fdesc1_info[op['name']]
+        ops.adam_filter_prep(self._fdesc1[off:], 1, blocks, self._small, 0, self.params, self.grads, m, v, alpha, beta1, beta2, eps, gscale, self.dtype)
+
+    def adam_update_small(self, m, v, alpha, beta1, beta2, eps, gscale):
+        """The parameters that are not filters (gamma, beta, biases) after every layer went through adam_update_layer."""
+        self._filter_descs()
+        ops.adam_filter_prep(self._fdesc, 0, 0, self._small, self._n_small, self.params, self.grads, m, v, alpha, beta1, beta2, eps, gscale, self.dtype)
         self._filters_dirty = False
 
     def _folds(self, op):

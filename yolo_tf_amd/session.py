@@ -1,5 +1,6 @@
 """Training / detection sessions: the counterpart of what the reference's callers drive through
 ``slim.learning.train`` (train.py:109-145) and ``sess.run`` (detect.py:69-71)."""
+import math
 import os
 
 import numpy as np
@@ -92,6 +93,15 @@ class TrainSession(object):
             e.dropout_rank = torch.distributed.get_rank()
         self.bucketed_update = True
         self.fuse_adam_prep = os.environ.get('YOLO2_FUSE_ADAM_PREP', '1') != '0'      # A/B: 0 = Adam launch + separate operand re-layout at the next forward
+        # Candidate, OFF by default (YOLO2_EARLY_ADAM=1 enables it): single process, Adam, no clipping -- a layer's filter is updated as soon as
+        # its gradient is final, on a third stream, while backward goes on (the update is HBM-bound, 0.36-0.41 ms as one launch at the end of the
+        # step; the 13x13 layers whose gradients come first hold 84 % of the parameters).  Bit-identical to the one-launch form (same kernel per
+        # layer, tests/test_network_gpu.py).  Measured SLOWER: 3.72 vs 3.62 ms per step (profiles/r05_early_adam.txt) -- the update's thousands
+        # of small workgroups (16.6 KB of LDS each) occupy CUs that the 150 KB convolution workgroups then cannot be placed on.
+        self.early_adam = (os.environ.get('YOLO2_EARLY_ADAM', '0') == '1' and world_size == 1 and optimizer == 'adam' and self.fuse_adam_prep
+                           and self.gradient_clip <= 0 and not getattr(e, '_has_l2', False) and dev.type == 'cuda')
+        self.opt_stream = torch.cuda.Stream(device=dev) if self.early_adam else None
+        self._early_pending = False
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
 
@@ -138,6 +148,23 @@ class TrainSession(object):
             # without clipping the optimizer consumes the buckets as they arrive (apply_gradients); clipping needs them all
             self._deferred = defer_collectives and self.gradient_clip <= 0 and self.bucketed_update
             self.reducer.finish(wait=not self._deferred)
+        elif self.early_adam and defer_collectives:
+            hp = self.optimizer.hp
+            t = self.global_step + 1
+            alpha = self.lr_fn(self.global_step) * math.sqrt(1.0 - hp['beta2'] ** t) / (1.0 - hp['beta1'] ** t)
+            main, opt, m_, v_ = torch.cuda.current_stream(), self.opt_stream, self.optimizer.slots[0], self.optimizer.slots[1]
+
+            def update_layer(op, wgrad_done):
+                # behind the layer's data gradient on the main stream (it reads the operand the update rewrites) and its filter gradient
+                ev = torch.cuda.Event()
+                ev.record(main)
+                opt.wait_event(ev)
+                if wgrad_done is not None:
+                    opt.wait_event(wgrad_done)
+                with torch.cuda.stream(opt):
+                    e.adam_update_layer(op, m_, v_, alpha, hp['beta1'], hp['beta2'], hp['epsilon'], 1.0)
+            e.backward(on_layer_done=update_layer)
+            self._early_pending = (alpha, hp['beta1'], hp['beta2'], hp['epsilon'])
         else:
             e.backward()
 
@@ -152,6 +179,14 @@ class TrainSession(object):
         else:
             gscale = 1.0 / self.world_size
         lr = self.lr_fn(self.global_step)
+        if self._early_pending:
+            # every filter was updated during backward (forward_backward); the small parameters follow once the updates have drained
+            alpha, b1, b2, eps = self._early_pending
+            self._early_pending = False
+            torch.cuda.current_stream().wait_stream(self.opt_stream)
+            e.adam_update_small(self.optimizer.slots[0], self.optimizer.slots[1], alpha, b1, b2, eps, 1.0)
+            self.global_step += 1
+            return
         if self.reducer is not None and getattr(self, '_sharded_pending', False):
             # the buckets' chains (reduce-scatter, shard update, all-gather) were enqueued during backward: wait for the last of them
             self.reducer.finish(wait=True)
