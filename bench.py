@@ -21,6 +21,8 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
   cpu_baseline  value = the torch-CPU (oneDNN) forward+backward of the same conv stack at batch 8 on the host cores (rank 0, N=1
                 only; oracle/torch_cpu_ref.py, a port: TF-1.0 cannot run here); sub-fields: the NumPy oracle's full training
                 step on one image (oracle/yolo2_ref.py) and the single-thread C restatement of the reference NMS
+  f32_parity_mode  the same step in the reference's own precision (exact-f32 MFMA), 10 steps outside the timed region: img/s and the
+                fraction of the 157.3 TFLOP/s f32 matrix peak
   detect        BASELINE configs[4]: batch-256 detect p50/p99 with (a) the network's own scores, (b) the sparse and
                 (c) the dense NMS stress inputs of BASELINE.md section 2 written over the decoded boxes
 """
@@ -224,6 +226,37 @@ def cpu_nms_baseline(classes):
     return res
 
 
+def f32_parity_mode(args, steps=10, warmup=3):
+    """The reference's own arithmetic is fp32 (TF-1.0 float32 graph): the same training step in the f32 parity mode -- exact-f32 MFMA
+    (v_mfma_f32_32x32x2_f32, 1/16 of the bf16 rate), the mode the 1e-4 oracle comparisons run in -- timed OUTSIDE the bench line's timed
+    region, so that the parity mode has a driver-observed number beside the bf16 one."""
+    from yolo_tf_amd.session import TrainSession
+    from yolo_tf_amd.utils import data
+    basedir = tempfile.mkdtemp(prefix='yolo_bench_f32_')
+    builder, cfg = make_builder('darknet', args.names, args.size, True, basedir)
+    sess = TrainSession(builder, args.batch, dtype='f32', optimizer='adam', learning_rate=1e-6, seed=0)
+    cells = args.size // 32
+    gen = torch.Generator(device='cuda').manual_seed(1234)
+    images = torch.rand(args.batch, args.size, args.size, 3, device='cuda', generator=gen) * 255.0
+    sess.upload_labels(data.synthetic_batch(args.batch, args.names, cells, cells, seed=4321))
+    for _ in range(warmup):
+        sess.step(images)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sess.step(images)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    loss = sess.fetch()['total_loss']
+    del sess
+    torch.cuda.empty_cache()
+    value = args.batch * steps / dt
+    tflops = value * TRAIN_GFLOP_PER_IMG[args.names] * (args.size / 416.0) ** 2 / 1e3
+    return {'value': value, 'unit': 'img/s', 'ms_per_step': dt / steps * 1e3, 'steps': steps, 'warmup': warmup, 'dtype': 'f32', 'batch': args.batch,
+            'whole_step_tflops': tflops, 'whole_step_frac_of_f32_matrix_peak': tflops / F32_MATRIX_PEAK_TFLOPS, 'peak_tflops': F32_MATRIX_PEAK_TFLOPS,
+            'total_loss': loss, 'note': 'same step and workload as the line itself in the f32 parity mode; outside the timed region'}
+
+
 def _lib_env_overrides():
     from yolo_tf_amd import _lib
     return _lib.env_overrides()
@@ -245,6 +278,7 @@ def main():
     ap.add_argument('--grad-dtype', default=None, choices=['f32', 'bf16'], help='wire format of the gradient all-reduce (N > 1); default: [mi355x] grad_dtype')
     ap.add_argument('--shard-optimizer', action='store_true', help='N > 1: reduce-scatter + 1/N optimizer pass + all-gather instead of all-reduce + replicated update ([mi355x] shard_optimizer)')
     ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'], help='process-group backend for N > 1 (default nccl = RCCL; gloo lets the tests run two ranks on one GPU)')
+    ap.add_argument('--no-f32', action='store_true', help='skip the f32 parity-mode sub-object (10 steps of the same workload in exact-f32 arithmetic, rank 0, N = 1)')
     ap.add_argument('--no-detect', action='store_true', help='skip the batch-256 detect p50/p99 report (BASELINE configs[4]) on rank 0')
     args = ap.parse_args()
 
@@ -389,6 +423,8 @@ def main():
                                'one_by_one_launches_same_template': {'tflops': k1['tflops'], 'launches': k1['launches'], 'avg_launch_ms': k1['avg_ms']} if k1 else None}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.names, args.size)
+        if world == 1 and not args.no_f32 and args.dtype == 'bf16':
+            out['f32_parity_mode'] = f32_parity_mode(args)
         if world == 1 and not args.no_detect:
             del sess
             torch.cuda.empty_cache()

@@ -2,7 +2,7 @@
 # the other BASELINE configurations + the batch fit on one box -> gpurun_out/other_configs.txt
 mkdir -p gpurun_out; out=gpurun_out/other_configs.txt; rm -f $out
 for a in "--batch 4" "--batch 8" "--batch 16" "--batch 32" "--batch 8 --names 80" "--batch 16 --dtype f32 --steps 10 --warmup 3" "--multiscale"; do
-  python bench.py $a --no-cpu-baseline --no-detect 2>/dev/null | tail -1 | python -c "
+  python bench.py $a --no-cpu-baseline --no-detect --no-f32 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$a ->', '%.0f img/s  %.3f ms/step' % (d['value'], d['ms_per_step']))" | tee -a $out
 done

@@ -41,15 +41,16 @@ def bf16_round(a):
 WORST = {}      # what -> worst measured error of the run, in units of the bound (printed per test; shown with pytest -s or on failure)
 
 
-def assert_close(got, ref, rtol, what=''):
+def assert_close(got, ref, rtol, what='', per_element=None):
     """fp32 claims against the oracle (rtol == F32_RTOL, north_star "within 1e-4 rel"): PER ELEMENT |err| <= rtol * |ref| + 0.1 * rtol * max|ref| -- relative where
     the reference is not small, with a floor of a tenth of the tolerance at the output scale for elements that are sums cancelling to ~0 (the
     f32 summation order of a 27k-term reduction moves those by ~1e-6 of the scale).  bf16-sized tolerances stay max-norm: the stored
     output's rounding is relative to each element and is tested per element in tests/test_bench_shapes_gpu.py; tighter tolerances (1e-6:
-    GPU path against GPU path, same products) are max-norm bounds on the summation order."""
+    GPU path against GPU path, same products) are max-norm bounds on the summation order, and so are whole-network comparisons
+    (per_element=False: 22 layers deep, a logit that cancels to ~0 carries the absolute error of its largest summand)."""
     got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
     scale = np.abs(ref).max() + 1e-30
-    if rtol == F32_RTOL:
+    if (rtol == F32_RTOL) if per_element is None else per_element:
         bound = rtol * np.abs(ref) + 0.1 * rtol * scale
         ratio = np.abs(got - ref) / bound
         worst = float(ratio.max()) if ratio.size else 0.0
@@ -236,6 +237,8 @@ TAP_CASES = [(s_, 'pp', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
 # (green on hardware: profiles/r05_tiny_tap_shapes.txt).
 _tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
 TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles') for s_ in _tiny]
+# batch-normalised outputs / producer activations are stored unpadded: those epilogues only with a filter count that is a multiple of 8
+TAP_CASES = [c_ for c_ in TAP_CASES if c_[2] in ('plain', 'bias_leaky') or c_[0][4] % 8 == 0]
 
 
 @pytest.mark.parametrize('shape,variant,epilogue', TAP_CASES, ids=['%s-%s-%s' % ('x'.join(map(str, c[0])), c[1], c[2]) for c in TAP_CASES])
@@ -268,8 +271,7 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
             elif epilogue == 'bias_leaky':
                 ops.conv2d_bias_leaky(xd, F, bias, O, ws, B, H, W, Cin, Cin, Cout, ldo, k, 0.1)
             elif epilogue == 'bn_stats':
-                if ldo != Cout:
-                    pytest.skip('batch-normalised outputs are stored unpadded')
+                assert ldo == Cout          # (batch-normalised outputs are stored unpadded: TAP_CASES pairs this epilogue with such shapes only)
                 part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
                 shift = dev(rng.randn(Cout).astype(np.float32) * 0.05) if tap == 0 else out[0][2][3]
                 mean, var = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
@@ -277,8 +279,7 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
                 ops.bn_finalize(part, shift, M, Cout, mean, var, None, None, 0.999)
                 extra = (mean, var, part, shift)
             else:
-                if ldo != Cout:
-                    pytest.skip('producer activations are stored unpadded')
+                assert ldo == Cout
                 if tap == 0:
                     yprev = dev(rng.randn(M, Cout).astype(np.float32) * 1.5 + 0.3, T)
                     pm, pv = dev(rng.randn(Cout).astype(np.float32) * 0.2 + 0.3), dev((rng.rand(Cout) + 0.5).astype(np.float32))
@@ -460,8 +461,11 @@ WGRAD_SHAPES += [(2, 13, 13, 96, 200, 3),     # ragged channel and filter tiles 
                  (3, 9, 31, 40, 72, 3)]
 
 
-@pytest.mark.parametrize('shape', WGRAD_SHAPES)
-@pytest.mark.parametrize('mode', list(WGRAD_MODES))
+# (the row-of-taps kernel takes 3x3 layers beyond the image layer: its forced variants are only paired with those shapes)
+WGRAD_CASES = [(s_, m_) for m_ in WGRAD_MODES for s_ in WGRAD_SHAPES if not (m_.startswith('bf16_row') and (s_[5] != 3 or s_[3] <= 8))]
+
+
+@pytest.mark.parametrize('shape,mode', WGRAD_CASES, ids=['%s-%s' % ('x'.join(map(str, c[0])), c[1]) for c in WGRAD_CASES])
 def test_conv_wgrad(ops, shape, mode):
     B, H, W, Cin, Cout, k = shape
     tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
@@ -473,8 +477,6 @@ def test_conv_wgrad(ops, shape, mode):
     ref = R.conv2d_wgrad(x, dy, k, k)
     ldx, ldy = ops.pad8(Cin), ops.pad8(Cout)
     dW = torch.zeros(k * k * Cin * Cout, dtype=torch.float32, device='cuda')
-    if mode.startswith('bf16_row') and (k != 3 or Cin <= 8):
-        pytest.skip('the row-of-taps kernel takes 3x3 layers beyond the image layer')
     ops.set_wgrad_variant(WGRAD_MODES[mode])
     try:
         ops.conv2d_wgrad(dev(pad_channels(x, ldx), tdtype), dev(pad_channels(dy, ldy), tdtype), dW, B, H, W, Cin, ldx, Cout, ldy, k)

@@ -133,7 +133,7 @@ def test_engine_logits_vs_reference_source(golden_dir, key, inference, names):
         ref = g[key + '/infer/logits']
         assert got.shape == ref.shape
         print('\nMEASURED inference logits %s fold_bn=%s: max abs err / max abs ref = %.3e' % (key, fold, np.abs(got - ref).max() / np.abs(ref).max()))
-        assert_close(got, ref, INFER_TOL, 'logits (fold_bn=%s)' % fold)
+        assert_close(got, ref, INFER_TOL, 'logits (fold_bn=%s)' % fold, per_element=False)
 
 
 TRAIN_CASES = [('yolo2_darknet', 'darknet', 20, TRAIN_TOL),        # 64x64: 2x2 cells x batch 2 = 8 samples per channel in the last stages
@@ -163,7 +163,7 @@ def test_engine_training_forward_vs_reference_source(golden_dir, key, inference,
     got = buf[:B * out.h * out.w * ld].float().cpu().numpy().reshape(B, out.h, out.w, ld)[..., :out.c]
     ref = g[key + '/train/logits']
     print('\nMEASURED training-mode logits %s: max abs err / max abs ref = %.3e' % (key, np.abs(got - ref).max() / np.abs(ref).max()))
-    assert_close(got, ref, tol, 'training-mode logits %s' % key)
+    assert_close(got, ref, tol, 'training-mode logits %s' % key, per_element=False)      # (whole network: max-norm, as pinned in round 4)
     var = e.get_variables()
     for k in [f for f in g.files if f.startswith(key + '/train/update/')]:
         name = k[len(key + '/train/update/'):]
