@@ -1,24 +1,45 @@
 #!/bin/bash
-R=$PWD; mkdir -p gpurun_out
-timeout 300 python scripts/conv_bench.py final 2>&1 | grep -v amdgpu.ids > gpurun_out/conv_final.txt
-cd /tmp; export TMPDIR=/tmp; rm -rf $R/gpurun_out/detprof
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/detprof -o run -- python $R/scripts/detect_prof.py 256 > $R/gpurun_out/detprof.log 2>&1
-cd $R
-python - <<PY > gpurun_out/detect_trace.md
-import sys; sys.path.insert(0,'scripts')
-from prof_summary import load, short
-rows=load('gpurun_out/detprof')
-nms=[i for i,r in enumerate(rows) if 'nms_kernel' in r[0]]
-sel=rows[nms[-6]+1:nms[-1]+1]
-agg={}
-for n,s,e in sel:
-    a=agg.setdefault(short(n)[:100],[0,0.0]); a[0]+=1; a[1]+=(e-s)/1e3
-tot=sum(v[1] for v in agg.values())
-print('# rocprofv3 --kernel-trace: batch-256 detect (scripts/detect_prof.py: standardise + forward with folded BN + decode + NMS on sparse scores), last 5 batches')
-print('kernel time per batch %.2f ms, %d launches\n' % (tot/5/1e3, len(sel)//5))
-print('| kernel | calls/batch | avg us | % |\n|---|---:|---:|---:|')
-for n,(c,t) in sorted(agg.items(), key=lambda kv:-kv[1][1]):
-    print('| \`%s\` | %.1f | %.1f | %.1f |' % (n, c/5, t/c, 100*t/tot))
-PY
-find gpurun_out/detprof -name "*.db" -size +30M -delete
-tail -3 gpurun_out/conv_final.txt; head -8 gpurun_out/detect_trace.md
+# ONE parametrised evidence script (replaces the per-experiment scripts/gpu_*.sh of rounds 1-4; they are in the git history).
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash scripts/gpu_evidence.sh r05 bench trace traffic pmc layers wgrad configs tests'
+# Every section runs on the box of THIS call, writes gpurun_out/<tag>_<section>.* with the box id and commit in its first lines (copy what is to be
+# judged into profiles/), and is bounded by its own timeout.  Sections:
+#   bench    python bench.py (the driver's line: roofline, cpu_baseline, f32_parity_mode, detect)
+#   trace    rocprofv3 --kernel-trace --stats of bench.py: product configuration + single stream, per-launch listing of the last step
+#   traffic  the same + FETCH_SIZE / WRITE_SIZE in separate PMC passes; refreshes the dominant kernel's bytes per launch
+#   pmc      SQ counters of forward + filter-gradient launches of six layers (scripts/one_layer.py), MFMA-busy calibrated on a pure MFMA loop
+#   layers   per-layer microbenchmark table (scripts/conv_bench.py)
+#   wgrad    filter gradient per layer, per-tap kernel vs the rule, batch 16 and 8, + the step A/B (scripts/gpu_w3.sh)
+#   configs  the other BASELINE configurations' single-GPU legs and the batch fit (scripts/gpu_other_configs.sh)
+#   tests    the whole -m gpu suite with durations
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out; TAG=${1:-ev}; shift
+make -C oracle >/dev/null 2>&1
+BOX="box: hostname $(hostname), GPU $(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id' | head -1 | sed 's/.*: *//'); commit $(cat .evidence_commit 2>/dev/null || echo '(snapshot)'); scripts/gpu_evidence.sh $TAG $* (ONE gpurun call)"
+echo "# $BOX" | tee gpurun_out/${TAG}_box.txt
+hdr() { echo "# $1"; echo "# $BOX"; echo; }
+for sec in "$@"; do
+  case $sec in
+    bench)
+      ( time timeout 600 python bench.py ) > gpurun_out/${TAG}_bench.log 2>&1
+      { hdr "python bench.py (defaults: N = 1, 100 steps, 10 warm-up)"; grep '^{' gpurun_out/${TAG}_bench.log | tail -1; grep -E '^real' gpurun_out/${TAG}_bench.log; } > gpurun_out/${TAG}_bench_line.txt
+      grep '^{' gpurun_out/${TAG}_bench.log | tail -1 | cut -c1-400 ;;
+    trace|traffic)
+      bash scripts/gpu_traffic.sh $([ $sec = trace ] && echo notraffic) > gpurun_out/${TAG}_traffic.log 2>&1
+      for f in prof_summary.md prof1s_summary.md prof1s_last_step.txt prof_roofline.txt traffic_summary.md; do
+        [ -f gpurun_out/$f ] && { hdr "$f of scripts/gpu_traffic.sh"; cat gpurun_out/$f; } > gpurun_out/${TAG}_$f
+      done
+      cat gpurun_out/prof_roofline.txt 2>/dev/null | tail -4 ;;
+    pmc)
+      bash scripts/gpu_pmc.sh > gpurun_out/${TAG}_pmc.log 2>&1
+      { hdr "SQ counters (scripts/gpu_pmc.sh)"; cat gpurun_out/pmc/calibration.txt gpurun_out/pmc_summary.md; } > gpurun_out/${TAG}_sq_counters.md; tail -14 gpurun_out/pmc_summary.md | cut -c1-260 ;;
+    layers)
+      { hdr "per-layer microbenchmark, batch 16 bf16 (scripts/conv_bench.py: 20 launches per hipGraph replay)"; timeout 600 python scripts/conv_bench.py $TAG 2>&1 | grep -v amdgpu.ids; } > gpurun_out/${TAG}_conv_layers.txt; tail -3 gpurun_out/${TAG}_conv_layers.txt ;;
+    wgrad)
+      rm -f gpurun_out/w3_step.log; bash scripts/gpu_w3.sh $TAG > gpurun_out/${TAG}_w3.log 2>&1; grep "passed\|failed\|^network\|wgrad variant" gpurun_out/${TAG}_w3.log ;;
+    configs)
+      bash scripts/gpu_other_configs.sh > gpurun_out/${TAG}_configs.log 2>&1; { hdr "other BASELINE configurations, single-GPU legs (scripts/gpu_other_configs.sh)"; cat gpurun_out/other_configs.txt; } > gpurun_out/${TAG}_other_configs.txt; cat gpurun_out/other_configs.txt ;;
+    tests)
+      ( time timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12 ) > gpurun_out/${TAG}_suite.log 2>&1
+      { hdr "python -m pytest tests -m gpu"; tail -22 gpurun_out/${TAG}_suite.log; } > gpurun_out/${TAG}_gpu_tests.txt; tail -4 gpurun_out/${TAG}_suite.log ;;
+    *) echo "unknown section $sec" ;;
+  esac
+done

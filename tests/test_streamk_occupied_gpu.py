@@ -53,6 +53,9 @@ def test_stream_k_beside_persistent_workgroups(ops, shape, occupied):
     ref, plan = conv()
     torch.cuda.synchronize()
     assert plan['split'] == 2 and plan['grid_x'] == cus, plan            # stream-K, one workgroup per CU
+    # the >= 1024-channel shapes run the ping-pong kernel (conv_pp.hip: deferred publication of a parked tail, relaxed agent-scope flag behind
+    # write-through stores) -- the hand-off this test exercises under reduced residency; the 512-channel forward whichever stream-K kernel the launch rule gives it
+    assert plan['stages'] == 18 or Cin < 1024, plan
     # ---- beside `occupied` persistent workgroups on a high-priority stream
     stop = torch.zeros(1, dtype=torch.int32, device='cuda')
     started = torch.zeros(1, dtype=torch.int32, device='cuda')
