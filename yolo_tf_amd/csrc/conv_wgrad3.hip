@@ -106,9 +106,13 @@ __global__ __launch_bounds__(WC *WN *KW * 64) void conv_wgrad_row_kernel(
     const int ncols = 3 * CT * NT;
     int col, by;
     if (remap == 2) {
+        // contiguous runs of the (range-major) workgroup list per XCD, bijective for any grid size: one range (13x13 stages) = the L2-stationary tile
+        // order; several ranges = every XCD works through one or two ranges' tiles back to back, whatever the range count (remap 1 needs a multiple
+        // of 8 ranges to load the XCDs evenly)
         const int ntile = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, qq = ntile >> 3, rr = ntile & 7;
-        col = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;       // bijective for any grid size
-        by = 0;
+        const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        by = w / ncols;
+        col = w - by * ncols;
     } else if (remap == 1) {
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         by = (idx / ncols) * 8 + xcd;
@@ -553,16 +557,16 @@ Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int for
     if (ks > max_ks) ks = max_ks;
     static const int env_ks = y2_env_int("YOLO2_W3_KS", 0), env_remap = y2_env_int("YOLO2_W3_REMAP", -1);      // (sweeps)
     if (env_ks > 0) ks = env_ks;
-    // >= 8 ranges are placed range-per-XCD (remap 1): a multiple of 8 keeps the XCDs evenly loaded (10 ranges gave two XCDs 48 workgroups and the
-    // others 24: the 52x52 layers ran 57 us instead of 39)
-    else if (ks >= 8) ks = ks / 8 * 8;
+    // >= 8 ranges placed range-per-XCD (remap 1) need a multiple of 8 to load the XCDs evenly (10 ranges gave two XCDs 48 workgroups and the others
+    // 24: the 52x52 layers ran 57 us instead of 39); YOLO2_W3_REMAP=2 takes contiguous runs per XCD instead and any range count
+    else if (ks >= 8 && env_remap != 2) ks = ks / 8 * 8;
     if ((v == 2 || v == 4) && force_variant < 0) ks = 1;
     p.qchunk = cdiv(cdiv(Mp, ks), step) * step;
     p.ks = cdiv(Mp, p.qchunk);
     p.variant = v;
     p.direct = p.ks == 1;
     p.remap = p.ks == 1 ? 2 : (p.ks >= 8 ? 1 : 0);
-    if (env_remap >= 0 && p.ks > 1) p.remap = env_remap ? 1 : 0;
+    if (env_remap >= 0 && p.ks > 1) p.remap = env_remap;
     p.blocks = (int)(p.remap == 1 ? ncols * (cdiv(p.ks, 8) * 8) : ncols * p.ks);
     p.BC = gm.BC; p.BN = gm.BN; p.waves = gm.waves;
     return p;
