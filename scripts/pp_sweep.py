@@ -11,8 +11,10 @@ LAYERS = [('conv5', 52, 128, 256), ('conv8', 26, 256, 512), ('conv13', 13, 512, 
 if os.environ.get('LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['LAYERS'].split(',')]
 B = int(os.environ.get('B', 16))
+SIZE = int(os.environ.get('SIZE', 416))      # network input size: the layers' image sizes scale with it (multi-scale training: 320 .. 608)
+LAYERS = [(l[0], l[1] * SIZE // 416) + tuple(l[2:]) for l in LAYERS]
 T = torch.bfloat16
-CONFIGS = [('per-tap', 0, 0, 0), ('pp-rule', 2, 0, 2), ('pp-sk', 2, 1, 2), ('pp-tile', 2, 2, 2)]
+CONFIGS = [('per-tap', 0, 0, 0), ('RULE', 2, 0, 2), ('pp-sk', 2, 1, 2), ('pp-tile', 2, 2, 2)]      # RULE = the product launch rule (its thresholds); the others force the kernel wherever it can run
 if os.environ.get('CONFIGS'):
     CONFIGS = [(c.split(':')[0],) + tuple(int(v) for v in c.split(':')[1:]) for c in os.environ['CONFIGS'].split(',')]
 WHAT = os.environ.get('WHAT', 'fwd+stats,dgrad,dgrad+bn').split(',')
@@ -70,7 +72,10 @@ for name, H, cin, cout in LAYERS:
     ref = {}
     for cname, mode, grid, sched in CONFIGS:
         ops.set_igemm_tap(mode)
-        ops.set_pp(grid=grid, dmapos=sched, min_steps=0, min_share=0)
+        if cname == 'RULE':
+            ops.set_pp(grid=0, dmapos=sched, min_steps=18, min_share=24)
+        else:
+            ops.set_pp(grid=grid, dmapos=sched, min_steps=0, min_share=0)
         for what in WHAT:
             fn, out = calls[what]
             try:

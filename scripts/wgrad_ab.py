@@ -9,6 +9,8 @@ from yolo_tf_amd import ops
 LAYERS = [('conv1', 208, 32, 64, 1), ('conv2', 104, 64, 128, 2), ('conv5', 52, 128, 256, 2), ('conv8', 26, 256, 512, 3),
           ('conv13', 13, 512, 1024, 3), ('conv18', 13, 1024, 1024, 2), ('conv20', 13, 3072, 1024, 1)]
 B = int(os.environ.get('B', 16))
+SIZE = int(os.environ.get('SIZE', 416))      # network input size: the layers' image sizes scale with it (multi-scale training: 320 .. 608)
+LAYERS = [(l[0], l[1] * SIZE // 416) + tuple(l[2:]) for l in LAYERS]
 if os.environ.get('LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['LAYERS'].split(',')]
 VARIANTS = [int(v) for v in os.environ.get('VARIANTS', '2,0,10,11,12').split(',')]
