@@ -5,7 +5,7 @@
 //
 //   dW[dh][dw][c][n] = sum_m X[pix(m) + (dh, dw), c] * dY[m, n]            (zero where the shifted pixel leaves the image)
 //
-// What the per-tap kernel of conv_wgrad.hip pays for, and what this one does instead:
+// What the per-tap kernel of conv_wgrad.hip pays for, and what this one does instead (DESIGN.md sections 3 and 5a):
 //   * it stages X once PER TAP (nine times) with the SAME-padding test in every DMA piece.  Here the reduction runs over a PADDED pixel
 //     index q: every image row is followed by one zero column (row pitch W + 1).  In that index the left / right neighbour of a pixel is
 //     q -+ 1 for EVERY pixel -- the neighbour of a row's first pixel is the previous row's zero column -- so one staged X tile, read at
@@ -14,13 +14,18 @@
 //     MFMA work is real (93 % at 13x13, 96 % at 26x26).
 //   * its waves hold 32 x 64 of ONE tap: 3 transpose reads per MFMA.  Here a wave holds 3 taps x 32 channels x 64 filters (six 32x32
 //     accumulators): the two dY fragments of a 16-pixel step are shared by the three taps, 10 reads per 6 MFMAs.
-//   * it pays one f32 atomic per output element and pixel range, ~5-7 M per launch on the 26x26 .. 104x104 layers (up to 35 us).  Here the
-//     KW wave groups of a workgroup take alternate pixel tiles of the workgroup's range and are summed through LDS before anything leaves
-//     the CU: one workgroup per CU, a quarter to an eighth of the atomics.
+//   * every barrier puts its eight waves into the same phase.  Here two wave groups run half a super-step apart: one in its MFMA phase (the
+//     next step's fragment reads in the MFMA gaps, counted lgkmcnt), the other issuing DMA and writing the next offset table.
+//   * it pays one f32 atomic per output element and pixel range, ~5-7 M per launch on the 26x26 .. 104x104 layers.  Here the KW wave groups
+//     of a workgroup take alternate pixel tiles of the workgroup's range and are summed through LDS before anything leaves the CU: one
+//     workgroup per CU, 2.4-3.1 M atomics per launch.
 // Tiles are staged pixel-major by LDS-DMA exactly as they lie in HBM and gathered with ds_read_b64_tr_b16 (layout and swizzle of
-// conv_wgrad.hip, pinned on hardware by tests/test_kernels_gpu.py::test_tr16_layout); the DMA source offsets are STATELESS: each piece
-// derives (row, column) of its padded position with two multiply-high divisions by constants (the per-tap kernel carried (h, w) per
-// piece slot through the loop).
+// conv_wgrad.hip, pinned on hardware by tests/test_kernels_gpu.py::test_tr16_layout; the +-1-row shifted reads are conflict-free:
+// SQ_LDS_BANK_CONFLICT = 0, profiles/r05_sq_counters.md).  DMA source offsets come from a per-stage table in LDS: one thread per staged ROW
+// derives (image row, column) of its padded position with two multiply-high divisions by constants -- stateless, and eight times less
+// arithmetic than every lane of every 1 KiB piece doing it for its own 16 bytes.
+// Measured (profiles/r05_wgrad_rule_vs_pertap*.txt): 13x13 layers 37.7 / 67.4 / 167.8 -> 31.6 / 57.9 / 159 us, 26x26 .. 104x104 layers 46-49 -> 38-39 us
+// at batch 16; what still bounds it is in DESIGN.md section 5a.
 #include "common.h"
 #include "conv_shared.h"
 #include <type_traits>
