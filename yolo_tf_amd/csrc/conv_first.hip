@@ -48,6 +48,22 @@ __device__ __forceinline__ void stage_halo(const __amdgpu_buffer_rsrc_t &rsrcX, 
     }
 }
 
+// this wave's first unit, its stride and the end of its XCD's band of units (grids that are a multiple of 8 blocks; else one band = all units)
+__device__ __forceinline__ void y2_first_band(int units, int wave, int &stride, int &u, int &uend) {
+    if ((gridDim.x & 7) == 0) {
+        const int nbx = gridDim.x >> 3, xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+        const int band = (units + 7) >> 3;
+        const int beg = xcd * band;
+        uend = min(units, beg + band);
+        u = beg + lb * 4 + wave;
+        stride = nbx * 4;
+    } else {
+        uend = units;
+        u = blockIdx.x * 4 + wave;
+        stride = gridDim.x * 4;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
@@ -86,18 +102,22 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const T *__restrict
     const float sh = bn_part ? bn_shift[n] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 
-    const int stride = gridDim.x * 4;
-    int u = blockIdx.x * 4 + wave;
-    if (u >= units) return;
+    // Units (32-pixel row segments) are dealt to the XCDs in contiguous BANDS (block b runs on XCD b % 8: observed, speed only): the three halo
+    // rows of a segment are the rows of the segments 13 units before and after it, and with units strided over the whole grid those ran on
+    // other XCDs at the same time -- every XCD's L2 fetched every image row about three times (148 MB for the 44 MB image,
+    // profiles/r04_hbm_traffic_pmc.md).  Inside a band they are L2 hits.
+    int stride, u, uend;
+    y2_first_band(units, wave, stride, u, uend);
+    if (u >= uend) return;
     auto decode = [&](int uu, int &b, int &h, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h = t % H; b = t / H; };
     int b, h, w0;
     decode(u, b, h, w0);
     stage_halo<T>(rsrcX, my, b, h, w0, H, W, lane);
     int st = 0;
-    for (; u < units; u += stride) {
+    for (; u < uend; u += stride) {
         const int un = u + stride;
         int nb = 0, nh = 0, nw0 = 0;
-        if (un < units) {
+        if (un < uend) {
             decode(un, nb, nh, nw0);
             stage_halo<T>(rsrcX, my + (st ^ 1) * SLOT, nb, nh, nw0, H, W, lane);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");   // everything older than the just-issued DMA has landed
@@ -200,9 +220,9 @@ __global__ __launch_bounds__(256) void conv_first_pool_kernel(const T *__restric
     const float dgm = MODE == 2 ? bn.dgamma[n] * invM : 0.f, dbm = MODE == 2 ? bn.dbeta[n] * invM : 0.f;
     float s0 = 0.f, s1 = 0.f;
 
-    const int stride = gridDim.x * 4;
-    int u = blockIdx.x * 4 + wave;
-    if (u >= units) return;
+    int stride, u, uend;
+    y2_first_band(units, wave, stride, u, uend);      // contiguous unit bands per XCD (see conv_first_fwd_kernel)
+    if (u >= uend) return;
     auto decode = [&](int uu, int &b, int &h2, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h2 = t % OH; b = t / OH; };
     auto stage = [&](unsigned char *dst, int b, int h2, int w0) {      // halo rows 2*h2-1 .. 2*h2+2, pixels w0-1 .. w0+32
         constexpr int HP = First<T>::HPIECES;
@@ -224,10 +244,10 @@ __global__ __launch_bounds__(256) void conv_first_pool_kernel(const T *__restric
     decode(u, b, h2, w0);
     stage(my, b, h2, w0);
     int st = 0;
-    for (; u < units; u += stride) {
+    for (; u < uend; u += stride) {
         const int un = u + stride;
         int nb = 0, nh2 = 0, nw0 = 0;
-        if (un < units) {
+        if (un < uend) {
             decode(un, nb, nh2, nw0);
             stage(my + (st ^ 1) * SLOT, nb, nh2, nw0);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
@@ -352,19 +372,19 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int stride = gridDim.x * 4;
-    int u = blockIdx.x * 4 + wave;
+    int stride, u, uend;
+    y2_first_band(units, wave, stride, u, uend);      // contiguous unit bands per XCD (see conv_first_fwd_kernel)
     auto decode = [&](int uu, int &b, int &h, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h = t % H; b = t / H; };
-    if (u < units) {
+    if (u < uend) {
         int b, h, w0;
         decode(u, b, h, w0);
         stage(my, b, h, w0);
     }
     const int g = lane >> 4, t16 = lane & 15;
     int st = 0;
-    for (; u < units; u += stride) {
+    for (; u < uend; u += stride) {
         const int un = u + stride;
-        if (un < units) {
+        if (un < uend) {
             int nb, nh, nw0;
             decode(un, nb, nh, nw0);
             stage(my + (st ^ 1) * SLOT, nb, nh, nw0);
@@ -452,7 +472,7 @@ bool y2_first_layer_shape(int Cp, int ldp, int Nf, int ldo, int ksize) { return 
 
 int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int W, int dtype, hipStream_t st, const float *bn_shift, float *bn_part) {
     const int units = B * H * ((W + 31) / 32);
-    const int grid = units / 4 + 1 < 2048 ? units / 4 + 1 : 2048;
+    const int grid = units / 4 + 8 < 2048 ? (units / 4 + 8) / 8 * 8 : 2048;      // (a multiple of 8: one band of units per XCD)
     // the forward filter operand is [32][9*8]: the generic layout with ldcin = 8
     if (dtype == YOLO2_BF16)
         conv_first_fwd_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)O, B, H, W, units, bn_shift, bn_part);
@@ -463,7 +483,7 @@ int y2_first_layer_fwd(const void *P, const void *F, void *O, int B, int H, int 
 
 int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int dtype, hipStream_t st) {
     const int units = B * H * ((W + 31) / 32);
-    const int grid = units / 4 + 1 < 512 ? units / 4 + 1 : 512;
+    const int grid = units / 4 + 8 < 512 ? (units / 4 + 8) / 8 * 8 : 512;
     if (dtype == YOLO2_BF16)
         conv_first_wgrad_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)X, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)dY, (unsigned)((size_t)B * H * W * 32 * 2), dW, B, H, W, Cin, units);
     else
@@ -477,7 +497,7 @@ template <int MODE>
 static int first_pool_launch(const void *P, const void *F, void *Out, unsigned char *idx, const void *dP, int lddp, float *part, int B, int H, int W, int ldo,
                              const Y2FirstBn &bn, int dtype, hipStream_t st) {
     const int units = B * (H / 2) * ((W + 31) / 32);
-    const int grid = units / 4 + 1 < 2048 ? units / 4 + 1 : 2048;
+    const int grid = units / 4 + 8 < 2048 ? (units / 4 + 8) / 8 * 8 : 2048;      // (a multiple of 8: one band of units per XCD)
     if (dtype == YOLO2_BF16)
         conv_first_pool_kernel<bf16, MODE><<<grid, 256, 0, st>>>((const bf16 *)P, (unsigned)((size_t)B * H * W * 8 * 2), (const bf16 *)F, (bf16 *)Out, idx, (const bf16 *)dP, lddp,
                                                                  part, B, H, W, ldo, units, bn);
