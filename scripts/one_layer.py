@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from yolo_tf_amd import ops
-LAYERS = {'conv2': (104, 64, 128, 3), 'conv5': (52, 128, 256, 3), 'conv8': (26, 256, 512, 3), 'conv13': (13, 512, 1024, 3), 'conv18': (13, 1024, 1024, 3), 'conv20': (13, 3072, 1024, 3)}
+LAYERS = {'conv1': (208, 32, 64, 3), 'conv2': (104, 64, 128, 3), 'conv5': (52, 128, 256, 3), 'conv8': (26, 256, 512, 3), 'conv13': (13, 512, 1024, 3), 'conv18': (13, 1024, 1024, 3), 'conv20': (13, 3072, 1024, 3)}
 B, T = 16, torch.bfloat16
 ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
 for name in sys.argv[1:]:

@@ -128,6 +128,8 @@ def test_forward_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
         assert plan['split'] == 2 and (plan['BM'], plan['stages']) == ((256, 18) if TAP_STAGES == 18 else (128, 3)), plan
     if name == 'conv8_10_12' and B == 16 and TAP_STAGES == 18:
         assert (plan['BM'], plan['stages'], plan['grid_x']) == (256, 18, 172), plan      # ping-pong kernel, one workgroup per tile (67 % of the CUs), no hand-off
+    if name == 'conv1' and 'YOLO2_C32' not in os.environ:
+        assert (plan['BM'], plan['BN'], plan['stages']) == (512, 64, 9), plan      # 32 -> 64 channels: the persistent kernel of conv_c32.hip (512-position tiles)
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', [c for c in _cases() if c.values[2] != 'conv0'])

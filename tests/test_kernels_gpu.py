@@ -98,6 +98,9 @@ CONV_SHAPES = [
     (1, 8, 8, 24, 64, 3),       # BN=64 tile, channel tail inside a K step
     (3, 5, 7, 136, 72, 3),      # odd extents, several K steps per tap
     (1, 13, 13, 192, 128, 3),   # three 64-channel K chunks forward, two in the data gradient
+    (2, 12, 20, 32, 64, 3),     # 32 -> 64 channels: the persistent conv1 kernel (conv_c32.hip), several tiles' worth of padded positions
+    (1, 7, 9, 32, 64, 3),       # ... one partial tile, odd extents
+    (3, 40, 33, 32, 64, 3),     # ... more tiles than one workgroup round leaves whole
     (2, 9, 11, 320, 200, 3),    # five chunks; data gradient single-chunk (ldy = 200)
 ]
 

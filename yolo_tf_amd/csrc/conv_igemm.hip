@@ -960,6 +960,18 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
     }
+    static const bool c32_direct = y2_env_int("YOLO2_C32", 1) != 0;
+    if (c32_direct && !bwd && y2_c32_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0) {      // 32 -> 64 channels (conv1): persistent kernel (conv_c32.hip)
+        const Tune tu = tune_now();
+        int rows = 0;
+        if (y2_c32_fwd(P, F, O, B, H, W, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
+            const int plan_[8] = {512, 64, 8, 8, 9, 0, rows, 1};
+            for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
+            if (bn_part) g_last_stat_rows = rows;
+            Y2_CHECK_LAUNCH();
+            return YOLO2_OK;
+        }
+    }
     bool stats_done = true;
     if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
         static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;

@@ -58,3 +58,9 @@ struct Y2W3Plan { int variant, ks, qchunk, blocks, remap, direct, BC, BN, waves;
 Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int force_variant);
 int y2_wgrad3_launch(const Y2W3Plan &p, const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t st);
 void y2_magic_u32(unsigned d, unsigned *m, unsigned *s);
+
+// conv_c32.hip: persistent 3x3 forward for 32-channel inputs and 64 filters (Darknet-19 conv1), bf16.  y2_c32_fwd returns non-zero when the image is
+// too wide for its LDS plan (the caller then takes the generic kernels).
+bool y2_c32_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
+int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
+               int cus, int *rows, hipStream_t st);
