@@ -212,6 +212,51 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
     np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('wgs,shape,c32', [(3, (3, 40, 33, 32, 64, 3), True),      # 9 tiles on 3 workgroups: three tiles each, both halo buffers reused
+                                            (2, (2, 12, 20, 32, 64, 3), True),       # 2 tiles, one per workgroup
+                                            (0, (1, 5, 300, 32, 64, 3), False)])     # a 300-wide row: two halo buffers do not fit LDS -> the generic kernel
+def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
+    """conv_c32.hip walks its tiles with one workgroup per CU; with the workgroup count forced down every workgroup takes several tiles
+    (the double-buffered halo, the per-lane statistics carried across tiles).  Output, bias + leaky and the fused batch-norm sums against
+    the oracle; the plan word says which kernel ran."""
+    B, H, W, Cin, Cout, k = shape
+    rng = np.random.RandomState(sum(shape) + 11)
+    x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
+    w = bf16_round((rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32) + 0.02)
+    bias = rng.randn(Cout).astype(np.float32)
+    T = torch.bfloat16
+    M = B * H * W
+    F = torch.zeros(Cout * k * k * Cin, dtype=T, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, Cout, T)
+    xd = dev(x, T)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    ref = R.conv2d(x, w)
+    try:
+        if wgs:
+            ops.set_stream_workgroups(wgs)
+        y = torch.zeros(M * Cout, dtype=T, device='cuda')
+        ops.conv2d_ws(xd, F, dev(bias), y, ws, B, H, W, Cin, Cin, Cout, Cout, k)
+        plan = ops.last_conv_plan()
+        assert ((plan['BM'], plan['BN'], plan['stages']) == (512, 64, 9)) == c32, plan
+        yb = torch.zeros(M * Cout, dtype=T, device='cuda')
+        part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
+        shift = dev((rng.randn(Cout) * 0.1).astype(np.float32))
+        mean, var = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+        ops.conv2d_bn(xd, F, yb, ws, B, H, W, Cin, Cin, Cout, Cout, k, shift, part)
+        planb = ops.last_conv_plan()
+        assert ((planb['BM'], planb['BN'], planb['stages']) == (512, 64, 9)) == c32, planb
+        ops.bn_finalize(part, shift, M, Cout, mean, var, None, None, 0.999)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_stream_workgroups(0)
+    assert_close(host(y).reshape(B, H, W, Cout), ref + bias, BF16_RTOL, 'c32 fwd + bias %s wgs %d' % (shape, wgs))
+    assert_close(host(yb).reshape(B, H, W, Cout), ref, BF16_RTOL, 'c32 fwd (bn) %s wgs %d' % (shape, wgs))
+    y64 = host(yb).astype(np.float64).reshape(M, Cout)
+    assert np.abs(host(mean) - y64.mean(0)).max() <= 2e-5 * np.sqrt(y64.var(0)).max() + 1e-6
+    assert np.abs(host(var) - y64.var(0)).max() <= 1e-4 * y64.var(0).max()
+    assert float(part.abs().max()) == 0.0
+
+
 def _bn_bwd_sums_oracle(dA, yprev, mean, var, gamma, beta, eps, alpha=0.1):
     """dgamma, dbeta of a = leaky(bn(yprev)) for the activation gradient dA, by the ORACLE's formulas (R.bn_apply, R.leaky_relu_grad,
     R.bn_train_bwd); inputs [M, C] float arrays."""

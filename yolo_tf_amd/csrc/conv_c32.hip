@@ -348,7 +348,7 @@ int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const
                                                           vecp, bn_part, alpha, mP, sP, mH, sH, abl);                                             \
     } while (0)
     if (bn_part) C32_LAUNCH(1, bn_shift);
-    else if (bias) C32_LAUNCH(2, bias);
+    else if (bias || alpha != 1.0f) C32_LAUNCH(2, bias);      // (an activation without a bias: the constants read as zeros)
     else C32_LAUNCH(0, (const float *)nullptr);
 #undef C32_LAUNCH
     if (rows) *rows = grid < Y2_BN_PART_ROWS ? grid : Y2_BN_PART_ROWS;
