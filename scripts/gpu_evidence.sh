@@ -13,7 +13,7 @@
 #   tests    the whole -m gpu suite with durations
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out; TAG=${1:-ev}; shift
 make -C oracle >/dev/null 2>&1
-BOX="box: hostname $(hostname), GPU $(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id' | head -1 | sed 's/.*Unique ID: *//'); commit $(cat .evidence_commit 2>/dev/null || echo '(snapshot)'); scripts/gpu_evidence.sh $TAG $* (ONE gpurun call)"
+BOX="box: hostname $(hostname), GPU $(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id: ' | head -1 | sed 's/.*Unique ID: *//'); commit $(cat .evidence_commit 2>/dev/null || echo '(snapshot)'); scripts/gpu_evidence.sh $TAG $* (ONE gpurun call)"
 echo "# $BOX" | tee gpurun_out/${TAG}_box.txt
 hdr() { echo "# $1"; echo "# $BOX"; echo; }
 for sec in "$@"; do

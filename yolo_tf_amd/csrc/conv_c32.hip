@@ -122,6 +122,7 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
     f32x2 t1[2][8], t2[2][8];                               // packed pairs: the sums run on v_pk_add_f32 / v_pk_fma_f32
     float *const shl = reinterpret_cast<float *>(hb + 2 * HB);
     if (MODE == 1 && tid < 64) shl[tid] = vec ? vec[tid] : 0.f;
+    if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the loop's barriers are raw: this write is on its way before the first one)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
