@@ -1,5 +1,5 @@
 """Where a workgroup of the 32 -> 64 channel forward kernel (conv_c32.hip) spends its time: s_memtime ticks per phase and tile of wave 0.
-Build conv_c32.hip with -DY2C32_EXPERIMENTS into a side library, then:
+Build the experiments library first (bash scripts/experiments_build.sh c32), then:
   YOLO2_LIB_PATH=.../libyolo2hip_exp.so YOLO2_C32_ABL=8 python scripts/c32_phase_cycles.py
 (YOLO2_C32_ABL bits 1 / 2 / 4 = no MFMA loop / no stores / no DMA after the first tile: timing ablations, wrong results)"""
 import os, sys, ctypes

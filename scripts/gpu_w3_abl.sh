@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing ablations of the row-of-taps filter-gradient kernel (experiments library: conv_wgrad3.hip -DY2W3_EXPERIMENTS; results wrong by design)
+# timing ablations of the row-of-taps filter-gradient kernel (experiments library: bash scripts/experiments_build.sh w3; results wrong by design)
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
 EXP=$R/yolo_tf_amd/csrc/libyolo2hip_exp.so
 { hostname; /opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i "unique"; } > gpurun_out/w3_box.txt 2>&1

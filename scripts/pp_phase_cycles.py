@@ -1,6 +1,6 @@
 """Where a K step of the ping-pong 3x3 kernel spends its shader cycles, measured inside the kernel (conv_pp.hip SCHED +4096 +512: s_memtime at the
 phase boundaries of every step, the epilogue's stores replaced by each wave's sums), and the shader clock the launch actually ran at
-(kernel cycles / kernel duration).  Needs the experiments library: bash scripts/pp_experiments_build.sh (on the host, before the gpurun call)
+(kernel cycles / kernel duration).  Needs the experiments library: bash scripts/experiments_build.sh pp (on the host, before the gpurun call)
 usage: YOLO2_LIB_PATH=$PWD/yolo_tf_amd/csrc/libyolo2hip_exp.so [B=16] [LAYERS=conv8,conv20] [GRID=0|1|2] python scripts/pp_phase_cycles.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

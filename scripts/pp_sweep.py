@@ -1,7 +1,7 @@
 """Per-layer A/B of the 3x3 implicit-GEMM variants on the Darknet-19 shapes (bf16): per-tap kernels (mode 0), the round-2 tap-fused kernel
 (mode 1: until commit 2e72607+3; gone since) and the ping-pong kernel (mode 2) as stream-K / one workgroup per tile with its SCHED variants
 (conv_pp.hip).  Every configuration's outputs are also compared with the per-tap kernels' on the same operands (max |diff| / max |ref|).
-usage: [YOLO2_LIB_PATH=.../libyolo2hip_exp.so for SCHED variants other than 2: scripts/pp_experiments_build.sh] B=16 [LAYERS=conv8,conv20] [CONFIGS=name:mode:grid:sched,...] python scripts/pp_sweep.py   -> us | TFLOP/s per launch, one box, hipGraph-replayed."""
+usage: [YOLO2_LIB_PATH=.../libyolo2hip_exp.so for SCHED variants other than 2: scripts/experiments_build.sh pp] B=16 [LAYERS=conv8,conv20] [CONFIGS=name:mode:grid:sched,...] python scripts/pp_sweep.py   -> us | TFLOP/s per launch, one box, hipGraph-replayed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

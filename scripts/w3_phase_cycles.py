@@ -1,4 +1,4 @@
-"""Where a workgroup of the row-of-taps filter-gradient kernel spends its shader cycles (conv_wgrad3.hip built with -DY2W3_EXPERIMENTS, YOLO2_W3_ABL=512:
+"""Where a workgroup of the row-of-taps filter-gradient kernel spends its shader cycles (conv_wgrad3.hip built with -DY2W3_EXPERIMENTS: bash scripts/experiments_build.sh w3, YOLO2_W3_ABL=512:
 s_memtime at the phase boundaries of every super-step).  usage: YOLO2_LIB_PATH=.../libyolo2hip_exp.so YOLO2_W3_ABL=512 [VARIANTS=12,13,14] python scripts/w3_phase_cycles.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
