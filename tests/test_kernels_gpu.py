@@ -238,6 +238,8 @@ def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
         ops.conv2d_ws(xd, F, dev(bias), y, ws, B, H, W, Cin, Cin, Cout, Cout, k)
         plan = ops.last_conv_plan()
         assert ((plan['BM'], plan['BN'], plan['stages']) == (512, 64, 9)) == c32, plan
+        yl = torch.zeros(M * Cout, dtype=T, device='cuda')
+        ops.conv2d_bias_leaky(xd, F, dev(bias), yl, ws, B, H, W, Cin, Cin, Cout, Cout, k, 0.1)      # the inference epilogue (folded BN): bias, leaky_relu
         yb = torch.zeros(M * Cout, dtype=T, device='cuda')
         part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
         shift = dev((rng.randn(Cout) * 0.1).astype(np.float32))
@@ -251,6 +253,8 @@ def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
         ops.set_stream_workgroups(0)
     assert_close(host(y).reshape(B, H, W, Cout), ref + bias, BF16_RTOL, 'c32 fwd + bias %s wgs %d' % (shape, wgs))
     assert_close(host(yb).reshape(B, H, W, Cout), ref, BF16_RTOL, 'c32 fwd (bn) %s wgs %d' % (shape, wgs))
+    z = ref + bias
+    assert_close(host(yl).reshape(B, H, W, Cout), np.maximum(z, np.float32(0.1) * z), BF16_RTOL, 'c32 fwd + bias + leaky %s wgs %d' % (shape, wgs))
     y64 = host(yb).astype(np.float64).reshape(M, Cout)
     assert np.abs(host(mean) - y64.mean(0)).max() <= 2e-5 * np.sqrt(y64.var(0)).max() + 1e-6
     assert np.abs(host(var) - y64.var(0)).max() <= 1e-4 * y64.var(0).max()
