@@ -53,6 +53,12 @@ int yolo2_shutdown(void);
  * convolution outputs produced since the previous check are invalid; the flag pool is reset and the process may continue.  The counterpart
  * of the reference surfacing failures as exceptions instead of hanging (utils/postprocess.py:22-35 asserts, detect.py:70 check_numerics). */
 int yolo2_check_async_errors(void *stream);
+/* The asynchronous form: enqueues on `stream` a copy of the current device's YOLO2_ASYNC_ERROR_WORDS give-up counters into caller-owned PINNED
+ * host memory and returns at once.  When the copy has completed (event / stream query) any non-zero word means yolo2_check_async_errors will
+ * report YOLO2_E_LAUNCH: a host polls this every step (no synchronisation, one 32-byte copy) and only pays for the synchronising call when
+ * something went wrong.  Same per-device semantics as yolo2_check_async_errors. */
+#define YOLO2_ASYNC_ERROR_WORDS 8
+int yolo2_async_error_snapshot(unsigned *host_words, void *stream);
 
 /* ---- workspace sizes, in bytes, of every entry that takes caller-owned scratch (`ws`): pure host queries ----------------
  * yolo2_conv2d_workspace_bytes: the largest scratch any variant of yolo2_conv2d_ws / _bn / _bias_leaky can use for the

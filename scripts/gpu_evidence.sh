@@ -11,6 +11,7 @@
 #   wgrad    filter gradient per layer, per-tap kernel vs the rule, batch 16 and 8, + the step A/B (scripts/gpu_w3.sh)
 #   configs  the other BASELINE configurations' single-GPU legs and the batch fit (scripts/gpu_other_configs.sh)
 #   tests    the whole -m gpu suite with durations
+#   rounds   same-box A/B of this tree's library against the previous round's (PREV=r05: profiles/baseline/libyolo2hip_r05.so), alternating
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out; TAG=${1:-ev}; shift
 make -C oracle >/dev/null 2>&1
 BOX="box: hostname $(hostname), GPU $(/opt/rocm/bin/rocm-smi --showuniqueid 2>/dev/null | grep -i 'unique id: ' | head -1 | sed 's/.*Unique ID: *//'); commit $(cat .evidence_commit 2>/dev/null || echo '(snapshot)'); scripts/gpu_evidence.sh $TAG $* (ONE gpurun call)"
@@ -40,6 +41,26 @@ for sec in "$@"; do
     tests)
       ( time timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=12 ) > gpurun_out/${TAG}_suite.log 2>&1
       { hdr "python -m pytest tests -m gpu"; tail -22 gpurun_out/${TAG}_suite.log; } > gpurun_out/${TAG}_gpu_tests.txt; tail -4 gpurun_out/${TAG}_suite.log ;;
+    rounds)
+      # THIS round's library against the previous round's (profiles/baseline/libyolo2hip_$PREV.so, scripts/build_baseline.sh) on THIS box, alternating:
+      # the bench step, the per-layer table (the 24 dominant launches, the filter gradients).  Every "round N vs N-1" number of README / DESIGN comes from here.
+      PREV=${PREV:-r05}; OLD=$R/profiles/baseline/libyolo2hip_$PREV.so
+      { hdr "same-box A/B: this tree's library vs $PREV ($(cat profiles/baseline/libyolo2hip_$PREV.commit 2>/dev/null | cut -c1-7)), alternating runs of ONE call"
+        if [ ! -f $OLD ]; then echo "no $OLD (bash scripts/build_baseline.sh $PREV <commit>)"; else
+        for i in 1 2 3; do for which in old new; do
+          if [ $which = old ]; then export YOLO2_LIB_PATH=$OLD YOLO2_LIB_BASELINE=1; else unset YOLO2_LIB_PATH YOLO2_LIB_BASELINE; fi
+          timeout 300 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-detect --no-f32 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        j=json.loads(l); r=j.get('roofline') or {}
+        print('step  %-3s run $i: %.3f ms/step %6.0f img/s   dominant launches %.2f us = %.3f of peak' % ('$which', j['ms_per_step'], j['value'], 1e3*(r.get('avg_launch_ms') or 0), r.get('frac') or 0))"
+        done; done
+        for which in old new old new; do
+          if [ $which = old ]; then export YOLO2_LIB_PATH=$OLD YOLO2_LIB_BASELINE=1; else unset YOLO2_LIB_PATH YOLO2_LIB_BASELINE; fi
+          echo "--- per-layer table, $which library"; timeout 600 python scripts/conv_bench.py $which 2>&1 | grep -v amdgpu.ids
+        done; unset YOLO2_LIB_PATH YOLO2_LIB_BASELINE; fi
+      } > gpurun_out/${TAG}_rounds_ab.txt 2>&1; grep -E "^step|network-weighted|igemm launches" gpurun_out/${TAG}_rounds_ab.txt ;;
     *) echo "unknown section $sec" ;;
   esac
 done

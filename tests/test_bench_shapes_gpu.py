@@ -12,7 +12,8 @@ variant ran (yolo2_debug_last_*_plan) and asserts it for the launches that carry
 Tolerance: operands are exact in bf16, products exact in f32, accumulation f32 on both sides -> the only differences are the
 summation order (~1e-6 of the output scale) and, for activations, the final bf16 rounding of the stored output
 (<= 2^-9 relative per element): |got - ref| <= 4e-3 |ref| + 2e-4 max|ref| per element; filter gradients (f32 out,
-f32 atomics over up to 173k pixels) 1e-3 of the scale like the toy-shape tests."""
+f32 atomics over up to 173k pixels) against the f64 sum of the same exact products, per element: 2e-5 |ref| + 4e-6 max|ref|
+(the f32 summation-order noise measures 0.4-1.3e-6 of the scale; a dropped border column of a padded-index kernel leaves 1e-2)."""
 import os
 
 import numpy as np
@@ -166,11 +167,12 @@ def test_wgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
     plan = ops.last_wgrad_plan()
     torch.cuda.synchronize()
     print('\nPLAN wgrad %s %s: %s accumulates=%s' % (cname, name, plan, accumulates))
-    ref = R.conv2d_wgrad(x, dy, k, k)
-    got = host(dW).reshape(k, k, cin, cout)
+    ref = R.conv2d_wgrad(x.astype(np.float64), dy.astype(np.float64), k, k)      # exact operands and products: the f64 sum is THE answer
+    got = host(dW).reshape(k, k, cin, cout).astype(np.float64)
     scale = float(np.abs(ref).max())
-    err = float(np.abs(got - ref).max())
-    assert err <= 1e-3 * scale, 'wgrad %s %s: max abs err %.3e vs scale %.3e' % (cname, name, err, scale)
+    ratio = np.abs(got - ref) / (2e-5 * np.abs(ref) + 4e-6 * scale)
+    print('wgrad %s %s: worst |err| / (2e-5 |ref| + 4e-6 scale) = %.3f; max |err| = %.2e of the scale' % (cname, name, ratio.max(), np.abs(got - ref).max() / scale))
+    assert ratio.max() <= 1.0, 'wgrad %s %s: %d elements beyond 2e-5 rel + 4e-6 of scale %.3e (worst ratio %.2f)' % (cname, name, int((ratio > 1).sum()), scale, ratio.max())
     if plan['BC'] > 0:
         assert bool(plan['direct']) == (not accumulates), plan
     cus = torch.cuda.get_device_properties(0).multi_processor_count
@@ -185,3 +187,45 @@ def test_wgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
             assert plan['blocks'] <= 3 * cus // 2 and plan['ranges'] * 3 * (cin // 64) * (cout // 64) <= cus, plan           # at most one workgroup per CU
         if name == 'conv1':
             assert plan['pair'] == 1, plan                                                                                # 32 input channels: per-tap kernel, two taps per tile
+
+
+@pytest.mark.parametrize('name,cin', [('conv13_15_17', 512), ('conv18_19', 1024), ('conv20', 3072)])
+def test_streamk_under_concurrent_row_wgrad(ops, name, cin):
+    """The product pairing of the backward pass (engine.Engine.backward): the stream-K forward / data-gradient launches hand partial tiles
+    between workgroups through flags on the main stream while the row-of-taps filter gradient (conv_wgrad3.hip: one ~150 KB-LDS workgroup per
+    CU) runs on a side stream and takes CUs the stream-K launch counted on.  A residency problem now gives a bounded wait and WRONG DATA, not a
+    hang, so: repeat the pair a few times with both in flight, check every element of all three results every time, and ask the device for
+    give-ups after each iteration."""
+    B, H, cout, k = 16, 13, 1024, 3
+    x, w, dy = _inputs(B, H, cin, cout, k, 4000 + cin)
+    ldx, ldy = cin, cout
+    xd, dyd = dev_bf16(x, ldx), dev_bf16(dy, ldy)
+    Ff = torch.zeros(cout * k * k * ldx, dtype=torch.bfloat16, device='cuda')
+    Fd = torch.zeros(cin * k * k * ldy, dtype=torch.bfloat16, device='cuda')
+    ops.filter_prep(torch.from_numpy(w).cuda(), Ff, Fd, k, cin, ldx, cout, ldy, torch.bfloat16)
+    ws = torch.zeros(WS_FLOATS, dtype=torch.float32, device='cuda')
+    ref_y, ref_dx = R.conv2d(x, w), R.conv2d_dgrad(dy, w)
+    ref_dw = R.conv2d_wgrad(x.astype(np.float64), dy.astype(np.float64), k, k)
+    scale_dw = float(np.abs(ref_dw).max())
+    side = torch.cuda.Stream()
+    for it in range(4):
+        O = torch.zeros(B * H * H * ldy, dtype=torch.bfloat16, device='cuda')
+        dx = torch.zeros(B * H * H * ldx, dtype=torch.bfloat16, device='cuda')
+        dW = torch.full((k * k * cin * cout,), float(it), dtype=torch.float32, device='cuda')      # (13x13: single range, plain stores over a dirty buffer)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            ops.conv2d_wgrad(xd, dyd, dW, B, H, H, cin, ldx, cout, ldy, k)
+            assert ops.last_wgrad_plan()['pair'] == 3, ops.last_wgrad_plan()
+        ops.conv2d_ws(dyd, Fd, None, dx, ws, B, H, H, ldy, ldy, cin, ldx, k)
+        plan_d = ops.last_conv_plan()
+        ops.conv2d_ws(xd, Ff, None, O, ws, B, H, H, ldx, ldx, cout, ldy, k)
+        plan_f = ops.last_conv_plan()
+        assert plan_f['split'] == 2 and plan_f['grid_x'] > 88, plan_f            # stream-K: more workgroups than tiles
+        if cin >= 1024:
+            assert plan_d['BM'] == 256 and plan_d['split'] == 2, plan_d
+        side.synchronize()
+        ops.check_async_errors()                                                  # (synchronises the main stream; raises on a give-up)
+        check_act(host(O).reshape(B, H, H, cout), ref_y, 'forward beside the row filter gradient, iteration %d' % it)
+        check_act(host(dx).reshape(B, H, H, cin), ref_dx, 'dgrad beside the row filter gradient, iteration %d' % it)
+        got = host(dW).reshape(k, k, cin, cout).astype(np.float64)
+        assert (np.abs(got - ref_dw) <= 2e-5 * np.abs(ref_dw) + 4e-6 * scale_dw).all(), 'filter gradient beside stream-K, iteration %d' % it

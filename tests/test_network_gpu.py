@@ -134,12 +134,14 @@ def test_train_step_matches_oracle(basedir, inference, size, dtype, B):
                 assert rel(params1[k], new_params[k]) <= 1e-4, k
 
 
-@pytest.mark.parametrize('inference,classes', [('darknet', 20), ('tiny', 20), ('darknet', 80), ('tiny', 80)])
-def test_detect_matches_oracle(basedir, inference, classes):
-    """Inference mode (BASELINE configs[0] is Tiny-YOLOv2 VOC-20 detect): moving-average BN folded into the filters, the tiny
-    model's stride-1 SAME pool, decode, NMS -- against the oracle's unfolded network on the same weights."""
+@pytest.mark.parametrize('inference,classes,B,size', [('darknet', 20, 2, 96), ('tiny', 20, 2, 96), ('darknet', 80, 2, 96), ('tiny', 80, 2, 96),
+                                                      ('tiny', 20, 1, 416)],      # BASELINE configs[0] at its stated size: ONE 416 x 416 image
+                         ids=['darknet-20', 'tiny-20', 'darknet-80', 'tiny-80', 'tiny-20-416x416-batch1'])
+def test_detect_matches_oracle(basedir, inference, classes, B, size):
+    """Inference mode (BASELINE configs[0] is Tiny-YOLOv2 VOC-20 detect, one 416 x 416 image: the last case; reference detect.py:59-91):
+    moving-average BN folded into the filters, the tiny model's stride-1 SAME pool, decode, NMS -- against the oracle's unfolded network on
+    the same weights, then the C restatement of utils/postprocess.py:39-51 on the very same scores."""
     from yolo_tf_amd.session import DetectSession
-    B, size = 2, 96
     b, _ = make_builder(inference, classes, size, False, basedir)
     sess = DetectSession(b, B, dtype='f32', seed=5)
     scope = 'yolo2_' + inference

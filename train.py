@@ -201,6 +201,14 @@ def main():
         want_summary = rank == 0 and (now - last_summary >= args.summary_secs or last)
         want_save = rank == 0 and now - last_save >= args.save_secs
         want_summary, want_save = agree([want_summary, want_save], device)
+        # device-detected failures (a stream-K tile owner that gave up waiting: include/yolo2_hip.h yolo2_check_async_errors).  The per-step
+        # snapshot is polled without a synchronisation; before anything is summarised or written the synchronising check runs.  Either way the
+        # error goes through agree() like shard_error below: one rank raising alone would leave its peers waiting in the next all-reduce, and
+        # a checkpoint must not be written from parameters that garbage gradients have updated.
+        dev_error = session.device_error() if (want_summary or want_save or last or session.async_error_pending()) else None
+        (bad_device,) = agree([dev_error is not None], device)
+        if bad_device:
+            raise dev_error if dev_error is not None else RuntimeError('another rank reported a device-side failure (stream-K hand-off gave up)')
         if want_summary:
             s = session.fetch()
             shard_error = None

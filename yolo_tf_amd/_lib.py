@@ -96,6 +96,7 @@ SIGNATURES = {
     'yolo2_cast_bf16_f32': [_p, _p, _l, _p],
     'yolo2_debug_occupy': [_i, _p, _p, _i, _p],
     'yolo2_check_async_errors': [_p],
+    'yolo2_async_error_snapshot': [_p, _p],
     'yolo2_debug_set_streamk_wait_us': [_i, _i],
 }
 
@@ -141,6 +142,7 @@ class FilterDesc(ctypes.Structure):
 
 
 _lib = None
+MISSING = set()      # entry points a baseline library (YOLO2_LIB_BASELINE=1) does not export
 
 
 def _mapped_hip_runtimes():
@@ -169,14 +171,32 @@ def load():
     runtimes = _mapped_hip_runtimes()
     if len(runtimes) > 1:
         raise HipKernelError('two HIP runtimes are mapped in this process (%s): something loaded %s before torch' % (', '.join(runtimes), LIB_PATH))
+    # Same-box A/B against an EARLIER round's library (profiles/baseline/libyolo2hip_rNN.so through YOLO2_LIB_PATH, scripts/gpu_evidence.sh
+    # section `rounds`): YOLO2_LIB_BASELINE=1 tolerates entry points that library predates -- calling one raises, nothing falls back.
+    baseline = os.environ.get('YOLO2_LIB_BASELINE') == '1' and bool(os.environ.get('YOLO2_LIB_PATH'))
+
+    def resolve(name):
+        try:
+            return getattr(lib, name)       # AttributeError if the symbol is not exported
+        except AttributeError:
+            if not baseline:
+                raise
+            MISSING.add(name)
+
+            def absent(*_args, _name=name):
+                raise HipKernelError('%s is not exported by the baseline library %s' % (_name, LIB_PATH))
+            setattr(lib, name, absent)
+            return None
     for name, (res, args) in QUERIES.items():
-        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
-        fn.restype = res
-        fn.argtypes = args
+        fn = resolve(name)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     for name, args in SIGNATURES.items():
-        fn = getattr(lib, name)
-        fn.restype = _i
-        fn.argtypes = args
+        fn = resolve(name)
+        if fn is not None:
+            fn.restype = _i
+            fn.argtypes = args
     _lib = lib
     over = env_overrides()
     if over:      # A/B switches select kernel variants: say so once, so that a run that differs from the tested defaults is not silent about it

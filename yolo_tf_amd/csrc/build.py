@@ -37,16 +37,21 @@ def _stale(out, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', os.path.join(ROCM, 'bin', 'hipcc'))
     headers = [os.path.join(HERE, 'common.h'), os.path.join(HERE, 'conv_shared.h'), os.path.join(HERE, '..', '..', 'include', 'yolo2_hip.h'), os.path.abspath(__file__)]
-    objs = []
+    objs, cmds = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)
         o = os.path.join(HERE, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ['-c', s, '-o', o]
-            if verbose:
-                print(' '.join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            cmds.append([hipcc] + COMMON + extra + ['-c', s, '-o', o])
         objs.append(o)
+    if cmds:      # independent translation units: compile them side by side (YOLO2_BUILD_JOBS, default: the CPUs of this host, at most 8)
+        from concurrent.futures import ThreadPoolExecutor
+        jobs = max(1, min(int(os.environ.get('YOLO2_BUILD_JOBS', min(8, os.cpu_count() or 1))), len(cmds)))
+        if verbose:
+            for cmd in cmds:
+                print(' '.join(cmd), flush=True)
+        with ThreadPoolExecutor(jobs) as pool:
+            list(pool.map(subprocess.check_call, cmds))
     if force or _stale(LIB, objs):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:

@@ -595,10 +595,8 @@ static unsigned *g_flag_pool[64] = {nullptr};
 static unsigned g_flag_counter[64] = {0};
 static std::atomic<unsigned> g_sk_wait_ticks{0};       // 0 = Y2_SK_DEFAULT_WAIT_TICKS (tests shorten it: yolo2_debug_set_streamk_wait_us)
 static std::atomic<int> g_sk_unclamped{0};             // tests only: lets a forced grid exceed the number of K steps (the partition bug the wait bound exists for)
-static unsigned *stream_flags() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(g_flag_mutex);
+// the current device's pool, created on first use (caller holds g_flag_mutex); does NOT advance the rotating set counter
+static unsigned *ensure_pool_locked(int dev) {
     if (!g_flag_pool[dev]) {
         unsigned *p = nullptr;
         const size_t bytes = (size_t)Y2_STREAM_FLAG_SETS * Y2_STREAM_FLAG_STRIDE * sizeof(unsigned);
@@ -606,10 +604,43 @@ static unsigned *stream_flags() {
         if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return nullptr; }
         g_flag_pool[dev] = p;
     }
-    return g_flag_pool[dev] + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_STRIDE;
+    return g_flag_pool[dev];
+}
+static unsigned *stream_flags() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_flag_mutex);
+    unsigned *pool = ensure_pool_locked(dev);
+    if (!pool) return nullptr;
+    return pool + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_STRIDE;
+}
+// Enqueues, on `stream`, a copy of the CURRENT device's give-up counters (one word per flag set) into caller-owned pinned host memory: the
+// asynchronous form of yolo2_check_async_errors.  A host that finds a non-zero word once the copy has completed (event / stream query) calls
+// yolo2_check_async_errors, which reports and re-zeroes the pool.  Costs one 32-byte device-to-host copy; nothing is synchronised.
+extern "C" int yolo2_async_error_snapshot(unsigned *host_words, void *stream) {
+    if (!host_words) { yolo2_set_error("yolo2_async_error_snapshot: host_words is NULL"); return YOLO2_E_ARG; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { yolo2_set_error("yolo2_async_error_snapshot: no current device"); return YOLO2_E_LAUNCH; }
+    unsigned *pool;
+    {
+        std::lock_guard<std::mutex> lock(g_flag_mutex);
+        pool = g_flag_pool[dev];
+    }
+    if (!pool) {      // no stream-K launch has run on this device yet: nothing can have given up
+        for (int i = 0; i < YOLO2_ASYNC_ERROR_WORDS; ++i) host_words[i] = 0u;
+        return YOLO2_OK;
+    }
+    static_assert(YOLO2_ASYNC_ERROR_WORDS == Y2_STREAM_FLAG_SETS, "one status word per flag set");
+    if (hipMemcpy2DAsync(host_words, sizeof(unsigned), pool + Y2_STREAM_FLAG_WORDS, Y2_STREAM_FLAG_STRIDE * sizeof(unsigned), sizeof(unsigned),
+                         Y2_STREAM_FLAG_SETS, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
+        yolo2_set_error("yolo2_async_error_snapshot: HIP error: %s", hipGetErrorString(hipGetLastError()));
+        return YOLO2_E_LAUNCH;
+    }
+    return YOLO2_OK;
 }
 // Synchronises `stream` and reports what only the device can know: a stream-K owner that gave up waiting for a partner's partial tile
 // (y2_sk_wait_and_clear).  The pool is re-zeroed so that the process can go on, but every result since the previous check is suspect.
+// Per device: reads and resets the pool of the CURRENT device only (a process driving several devices checks each under hipSetDevice).
 extern "C" int yolo2_check_async_errors(void *stream) {
     int dev = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
@@ -638,14 +669,14 @@ extern "C" int yolo2_check_async_errors(void *stream) {
 // tests: wait limit of the stream-K owners in microseconds (0 = default, 2 s) and the grid clamp (unclamped != 0 lets yolo2_debug_set_pp force
 // more workgroups than K steps -- an unserviceable partition)
 extern "C" int yolo2_debug_set_streamk_wait_us(int us, int unclamped) {
-    if (us < 0) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: us < 0"); return YOLO2_E_ARG; }
+    if (us < 0 || (unsigned)us > 0xffffffffu / 100u) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: us outside 0 .. %u (100 MHz ticks in 32 bits)", 0xffffffffu / 100u); return YOLO2_E_ARG; }
     const unsigned ticks = (unsigned)us * 100u;
     g_sk_wait_ticks.store(ticks, std::memory_order_relaxed);
     g_sk_unclamped.store(unclamped, std::memory_order_relaxed);
-    if (!stream_flags()) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: no flag pool"); return YOLO2_E_LAUNCH; }
     int dev = 0;
-    (void)hipGetDevice(&dev);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: no current device"); return YOLO2_E_LAUNCH; }
     std::lock_guard<std::mutex> lock(g_flag_mutex);
+    if (!ensure_pool_locked(dev)) { yolo2_set_error("yolo2_debug_set_streamk_wait_us: no flag pool"); return YOLO2_E_LAUNCH; }
     (void)hipDeviceSynchronize();
     for (int i = 0; i < Y2_STREAM_FLAG_SETS; ++i)
         if (hipMemcpy(g_flag_pool[dev] + (size_t)i * Y2_STREAM_FLAG_STRIDE + Y2_STREAM_FLAG_WORDS + 1, &ticks, sizeof(ticks), hipMemcpyHostToDevice) != hipSuccess)

@@ -12,8 +12,10 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 // The owner of a stream-K tile waits for the flag of partner workgroup p (called by ONE lane) and clears it.  The wait is bounded: a partition
 // bug (a workgroup without work never raises its flag -- the hang behind launch_conv's grid clamp) or a lost partner must surface as an error,
-// not as a hung device.  On a time-out the launch's results are wrong by construction; the status word makes yolo2_check_async_errors() (and every
-// later stream-K launch of this process) return YOLO2_E_LAUNCH.  The fast path (flag already up) costs one load, as before.
+// not as a hung device.  On a time-out the launch's results are wrong by construction (the owner sums an unfinished slot, and the late partner's
+// flag may be consumed by a later launch of the same flag set): the status word makes yolo2_check_async_errors() return YOLO2_E_LAUNCH and re-zero
+// the pool; hosts bound the exposure by polling it every step without a synchronisation (yolo2_async_error_snapshot: TrainSession.step,
+// DetectSession.detect) and before anything is written to disk.  The fast path (flag already up) costs one load, as before.
 __device__ __forceinline__ void y2_sk_wait_and_clear(unsigned *flags, int p) {
     if (__hip_atomic_load(flags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
         const unsigned cfg = __hip_atomic_load(flags + Y2_STREAM_FLAG_WORDS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -352,6 +352,33 @@ def check_async_errors():
     call('yolo2_check_async_errors', _stream())
 
 
+class AsyncErrorPoll(object):
+    """yolo2_async_error_snapshot without a synchronisation: ``snapshot()`` enqueues the 32-byte copy of the device's give-up counters into
+    pinned host memory behind the work already on the current stream; ``pending()`` says whether a COMPLETED snapshot shows a failure (then
+    ``check_async_errors()`` raises with the library's message and resets the pool).  One step of latency instead of one summary interval."""
+
+    def __init__(self):
+        self.words = torch.zeros(8, dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def snapshot(self):
+        _lib.load()
+        if 'yolo2_async_error_snapshot' in _lib.MISSING:      # an earlier round's library in a same-box A/B (YOLO2_LIB_BASELINE=1)
+            return
+        call('yolo2_async_error_snapshot', self.words.data_ptr(), _stream())
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def pending(self):
+        return self.event is not None and self.event.query() and bool(self.words.any().item())
+
+    def raise_if_pending(self):
+        if self.pending():
+            self.event = None
+            check_async_errors()
+            raise RuntimeError('stream-K hand-off gave up (reported by yolo2_async_error_snapshot); convolution outputs since the last check are invalid')
+
+
 def set_streamk_wait_us(us=0, unclamped=False):
     """Test hook: wait limit of the stream-K owners (0 = default 2 s) and the grid <= K-steps clamp."""
     call('yolo2_debug_set_streamk_wait_us', int(us), int(bool(unclamped)))

@@ -102,6 +102,9 @@ class TrainSession(object):
                            and self.gradient_clip <= 0 and not getattr(e, '_has_l2', False) and dev.type == 'cuda')
         self.opt_stream = torch.cuda.Stream(device=dev) if self.early_adam else None
         self._early_pending = False
+        self._in_step = False            # the early-update candidate only runs inside step(): forward_backward() + apply_gradients() as one unit
+        # device-detected failures (a stream-K tile owner that gave up, conv_shared.h) polled every step without a synchronisation
+        self.async_errors = ops.AsyncErrorPoll() if dev.type == 'cuda' else None
         # arena offset below which every gradient is final once a given layer's backward has run
         self._layer_end = layer_end_offsets(e.graph, e.param_offsets)
 
@@ -122,6 +125,7 @@ class TrainSession(object):
         """Gradients are final (all-reduced) on return unless ``defer_collectives``: then the buckets may still be on the wire
         and ``apply_gradients`` consumes them one by one (what ``step`` does)."""
         e, m = self.engine, self.model
+        assert not self._early_pending, 'a layer-wise early update is half applied: apply_gradients() must follow the forward_backward() of step()'
         e.dropout_step = self.global_step
         e.zero_grads()
         e.set_images(images, self.preprocess_mode)
@@ -148,7 +152,7 @@ class TrainSession(object):
             # without clipping the optimizer consumes the buckets as they arrive (apply_gradients); clipping needs them all
             self._deferred = defer_collectives and self.gradient_clip <= 0 and self.bucketed_update
             self.reducer.finish(wait=not self._deferred)
-        elif self.early_adam and defer_collectives:
+        elif self.early_adam and defer_collectives and self._in_step:
             hp = self.optimizer.hp
             t = self.global_step + 1
             alpha = self.lr_fn(self.global_step) * math.sqrt(1.0 - hp['beta2'] ** t) / (1.0 - hp['beta1'] ** t)
@@ -221,10 +225,34 @@ class TrainSession(object):
         self.optimizer_state_complete = True
 
     def step(self, images, labels=None):
+        # a failure the device reported during an EARLIER step (completed snapshot): a single process raises here, one step late instead of one
+        # summary interval; data-parallel callers read async_error_pending() / device_error() and agree on it first (train.py) -- a rank
+        # that raised alone would leave its peers waiting in the next collective
+        if self.async_errors is not None and self.world_size == 1:
+            self.async_errors.raise_if_pending()
         if labels is not None:
             self.upload_labels(labels)
-        self.forward_backward(images, defer_collectives=True)
-        self.apply_gradients()
+        self._in_step = True
+        try:
+            self.forward_backward(images, defer_collectives=True)
+            self.apply_gradients()
+        finally:
+            self._in_step = False
+        if self.async_errors is not None:
+            self.async_errors.snapshot()
+
+    def async_error_pending(self):
+        """True when a completed per-step snapshot shows a device-detected failure (no synchronisation)."""
+        return self.async_errors is not None and self.async_errors.pending()
+
+    def device_error(self):
+        """Synchronises and RETURNS the device-detected failure (an exception object) or None: data-parallel callers put it through agree()
+        and raise on every rank (train.py), single-process callers may simply call fetch()."""
+        try:
+            ops.check_async_errors()
+        except RuntimeError as exc:
+            return exc
+        return None
 
     def fetch(self):
         """Synchronises and returns {'total_loss', 'iou_best', 'iou_normal', 'coords', 'prob'} of the last step
@@ -263,6 +291,7 @@ class DetectSession(object):
         self._attrs = None
         m.bind(self)                 # Model.conf / xy_min / xy_max / iou / prob / xy / wh read this session's buffers
         self.nms_ws = torch.zeros(ops.workspace_bytes('nms', batch_size, n, self.C) // 4, dtype=torch.int32, device=dev)
+        self.async_errors = ops.AsyncErrorPoll()
 
     def run(self, images, preprocess_mode=0, check_numerics=True):
         """images: device f32 [B,H,W,3].  Returns device tensors conf [B,N,C], xy_min, xy_max [B,N,2]
@@ -278,8 +307,15 @@ class DetectSession(object):
         else:
             ops.head_decode(logits, ld, self.anchors, self.conf, self.xy_min, self.xy_max, self.nan_flag, self.B, m.cell_height,
                             m.cell_width, self.A, self.C)
-        if check_numerics and int(self.nan_flag.item()) != 0:
-            raise FloatingPointError('conf/xy_min/xy_max : Tensor had NaN or Inf values')
+        if check_numerics:
+            bad = int(self.nan_flag.item()) != 0           # (synchronises: the device-side failure check below then costs one small copy)
+            ops.check_async_errors()                      # a stream-K hand-off that gave up: these scores are garbage -- raise like check_numerics
+            if bad:
+                raise FloatingPointError('conf/xy_min/xy_max : Tensor had NaN or Inf values')
+        else:
+            # benchmark / pipelined callers: no synchronisation here; a failure of an EARLIER run raises now, this run's is polled by the next
+            self.async_errors.raise_if_pending()
+            self.async_errors.snapshot()
         return self.conf, self.xy_min, self.xy_max
 
     def attrs(self):
