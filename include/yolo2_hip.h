@@ -428,15 +428,22 @@ int yolo2_selftest_tr16(short *out, void *stream);
 int yolo2_debug_last_conv_plan(int *out8);
 /* measurement hook: launches an empty kernel (bench.py calibrates the overhead of its HIP-event brackets with it) */
 int yolo2_debug_noop(void *stream);
-/* test hook (process-wide): 0 = per-tap 3x3 kernels only; non-zero = the ping-pong tap-fused kernel (csrc/conv_pp.hip) wherever its
- * launch rule admits it (default) */
+/* test hook (process-wide): 0 = per-tap 3x3 kernels only; 2 (and any other non-zero value) = the ping-pong tap-fused kernel (csrc/conv_pp.hip) wherever
+ * its launch rule admits it; 3 = the loader / consumer member of the same family under the same rule (csrc/conv_s4.hip: four computing waves of
+ * 128 x 64 + four loader waves; plan word `waves` = 4).  YOLO2_IGEMM_TAP sets the initial value. */
 int yolo2_debug_set_igemm_tap(int mode);
+/* experiments build of csrc/conv_s4.hip only (timing ablations, phase stamps); ignored by the product build */
+int yolo2_debug_set_s4_abl(int abl);
 /* test / A-B hook for the ping-pong kernel.  grid: 0 = by rule (default), 1 = stream-K over one workgroup per CU, 2 = one workgroup per
  * tile, >= 8 = that many workgroups, <= -2 = every tile cut into exactly -grid shares, -1 = keep; a stream-K grid never exceeds the
  * number of K steps.  sched: the kernel's LOAD-phase order (2 in the product build; others only in scripts/pp_experiments_build.sh's;
  * an order the library was not built with sends the layer to the per-tap kernels).  min_steps / min_share: the rule's gates (K steps
  * per tile, K steps per workgroup).  A negative argument keeps the current value. */
 int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
+/* tests / A-B: cost units (in K steps) the stream-K partition of the ping-pong kernel charges to the workgroup that owns a tile -- it also waits for
+ * and sums its partners' partial tiles and runs the epilogue, so it gets up to that many fewer K steps (csrc/conv_pp.hip "cost-balanced shares");
+ * 0 = equal K-step shares.  The library clamps it below half a share.  YOLO2_PP_CV sets the initial value. */
+int yolo2_debug_set_pp_cost(int cv);
 /* tests: the stream-K owners' wait limit in microseconds (0 = the default, 2 s); unclamped != 0 lets a grid forced through yolo2_debug_set_pp
  * exceed the number of K steps -- a partition no owner can be served by, which must end in yolo2_check_async_errors() == YOLO2_E_LAUNCH */
 int yolo2_debug_set_streamk_wait_us(int us, int unclamped);

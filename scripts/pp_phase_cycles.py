@@ -13,7 +13,7 @@ if os.environ.get('LAYERS'):
 B = int(os.environ.get('B', 16))
 GRID = int(os.environ.get('GRID', 0))
 T = torch.bfloat16
-SCHED_TIME, SCHED_NOEPI = 2 + 512 + 4096, 2 + 512
+SCHED_TIME, SCHED_NOEPI = 2 + 512 + 4096 + int(os.environ.get('ABL', 0)), 2 + 512      # ABL: +256 no DMA in the loop, +128 no fragment reads, +64 no MFMAs (stamped launch only)
 ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
 
 

@@ -293,20 +293,21 @@ def _bn_bwd_sums_oracle(dA, yprev, mean, var, gamma, beta, eps, alpha=0.1):
 TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 256), (8, 13, 13, 1024, 504), (16, 26, 26, 256, 136),
               (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256)]
 # variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong SCHED (-1 = the default))
-TAP_VARIANTS = {'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1)}
+# s4 / s4_tiles: the loader / consumer member of the family (conv_s4.hip: four computing waves of 128 x 64 + four loader waves; plan word waves == 4)
+TAP_VARIANTS = {'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1), 's4': (3, 1, -1), 's4_tiles': (3, 2, -1)}
 _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant and epilogue: minutes of CPU time when recomputed 12 times)
 
 
 TAP_EPILOGUES = ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn']
 # stream-K: every shape x every epilogue.  One workgroup per tile: the bench shapes the launch rule gives a tile grid (26x26 256->512 forward,
 # 52x52 / 55x55 data gradients).
-TAP_CASES = [(s_, 'pp', e_) for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
-            [(s_, 'pp_tiles', e_) for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
+TAP_CASES = [(s_, v_, e_) for v_ in ('pp', 's4') for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
+            [(s_, v_, e_) for v_ in ('pp_tiles', 's4_tiles') for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
 # Shapes with fewer K steps than CUs (odd sizes, partial tiles, 3 and 5 chunks, H != W).  A forced stream-K grid used to leave workgroups without
 # work whose flags an owner then waited for (a hang, found by these shapes); launch_conv clamps the grid to the number of K steps
 # (green on hardware: profiles/r05_tiny_tap_shapes.txt).
 _tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
-TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles') for s_ in _tiny]
+TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles', 's4', 's4_tiles') for s_ in _tiny]
 # batch-normalised outputs / producer activations are stored unpadded: those epilogues only with a filter count that is a multiple of 8
 TAP_CASES = [c_ for c_ in TAP_CASES if c_[2] in ('plain', 'bias_leaky') or c_[0][4] % 8 == 0]
 
@@ -365,6 +366,8 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
             plan = ops.last_conv_plan()
             torch.cuda.synchronize()
             assert (plan['stages'] == 18) == bool(tap and Cout > 64), plan
+            if tap and Cout > 64:
+                assert plan['waves'] == (4 if mode == 3 else 8), plan
             if tap and pp_grid == 2:
                 assert plan['grid_x'] == -(-M // 256) * -(-Cout // 128), plan
             out[tap] = (host(O).reshape(M, ldo), plan, extra)

@@ -114,6 +114,8 @@ QUERIES = {
     'yolo2_debug_last_conv_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_set_pp': (_i, [_i, _i, _i, _i]),
+    'yolo2_debug_set_pp_cost': (_i, [_i]),
+    'yolo2_debug_set_s4_abl': (_i, [_i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_wgrad_row_plan': (_i, [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
     'yolo2_debug_magic_u32': (_i, [ctypes.c_uint, ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]),

@@ -11,6 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = {
     'conv_igemm.hip': [],
     'conv_pp.hip': [],
+    'conv_s4.hip': [],
     'conv_wgrad.hip': [],
     'conv_wgrad3.hip': [],
     'conv_c32.hip': [],

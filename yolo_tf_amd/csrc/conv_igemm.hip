@@ -790,9 +790,15 @@ static constexpr bool igemm_wide_fits() {
 // tests can compare both variants on the same inputs
 // 0 = per-tap kernels only, non-zero = the ping-pong tap-fused kernel (conv_pp.hip) where its launch rule admits it (default).  (The round-2
 // tap-fused kernel it replaced -- slower on every layer it took, profiles/r04_pp2_sched_b16.txt column tap-r2 -- is gone.)
+// 3 = the loader / consumer member of the tap-fused family (conv_s4.hip: four computing waves of 128 x 64 + four loader waves), same launch rule
 static std::atomic<int> g_igemm_tap{y2_env_int("YOLO2_IGEMM_TAP", 2)};
 extern "C" int yolo2_debug_set_igemm_tap(int mode) {
-    g_igemm_tap.store(mode != 0 ? 2 : 0, std::memory_order_relaxed);
+    g_igemm_tap.store(mode == 3 ? 3 : (mode != 0 ? 2 : 0), std::memory_order_relaxed);
+    return YOLO2_OK;
+}
+static std::atomic<int> g_s4_abl{0};      // experiments build of conv_s4.hip: timing ablations / phase stamps (yolo2_debug_set_s4_abl)
+extern "C" int yolo2_debug_set_s4_abl(int abl) {
+    g_s4_abl.store(abl, std::memory_order_relaxed);
     return YOLO2_OK;
 }
 // ping-pong kernel knobs (A/B runs and tests): grid 0 = by rule, 1 = stream-K (one workgroup per CU), 2 = one workgroup per tile;
@@ -802,6 +808,13 @@ static std::atomic<int> g_pp_dmapos{y2_env_int("YOLO2_PP_SCHED", 2)};      // co
 static std::atomic<long> g_pp_min_steps{18};
 static std::atomic<long> g_pp_min_share{24};
 static const int g_pp_long_share = y2_env_int("YOLO2_PP_LONG_SHARE", 26);      // (0 = round 4's rule, for the A/B)
+// cost units charged to the owner of a stream-K tile, in K steps (conv_pp.hip "cost-balanced shares"); 0 = equal K-step shares (round 5)
+static std::atomic<int> g_pp_cv{y2_env_int("YOLO2_PP_CV", 0)};
+extern "C" int yolo2_debug_set_pp_cost(int cv) {
+    if (cv < 0 || cv > 4096) { yolo2_set_error("yolo2_debug_set_pp_cost: 0 .. 4096 K steps"); return YOLO2_E_ARG; }
+    g_pp_cv.store(cv, std::memory_order_relaxed);
+    return YOLO2_OK;
+}
 extern "C" int yolo2_debug_set_pp(int grid, int dmapos, int min_steps, int min_share) {
     if (grid != -1) g_pp_grid.store(grid, std::memory_order_relaxed);
     if (dmapos >= 0) g_pp_dmapos.store(dmapos, std::memory_order_relaxed);
@@ -894,8 +907,20 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
                 const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
+                // owner cost of the cost-balanced partition: below half a workgroup's share, so that every workgroup keeps real K steps (an owner
+                // waits for the flag of every workgroup inside its tile); whole-tile grids have no shares to balance
+                int cv = grid == tiles_t ? 0 : g_pp_cv.load(std::memory_order_relaxed);
+                if (cv > units_p / grid / 2) cv = (int)(units_p / grid / 2);
+                g_last_plan[7] = 1 + (cv << 8);      // plan word grid_y: bits 8.. = the owner cost in use
+                if (tap_mode == 3) {
+                    g_last_plan[2] = 4;             // plan word waves: four COMPUTING waves (+ four loaders)
+                    if (y2_conv3x3_s4_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_, 1, grid,
+                                             g_s4_abl.load(std::memory_order_relaxed), st) == 0)
+                        return 0;
+                    g_last_plan[2] = 8;
+                }
                 if (y2_conv3x3_pp_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_,
-                                         /* K rotation of the stream-K tiles (profiles/r03_l2_stationary_ab.md) */ 1, grid, g_pp_dmapos.load(std::memory_order_relaxed), st) == 0)
+                                         /* K rotation of the stream-K tiles (profiles/r03_l2_stationary_ab.md) */ 1, grid, g_pp_dmapos.load(std::memory_order_relaxed), cv, st) == 0)
                     return 0;
             }
         }

@@ -72,11 +72,19 @@ constexpr int y2p_leave_m(int D, int tp, int hslots, bool skipidle) {
 //    the code is in the history of this file)
 //   +8  slots of taps >= HSLOTS carry no halo piece at all (2 instead of 3 instructions; the counted waits use the exact per-tap sums)
 //   +16 s_setprio 1 for the MFMA phase
+#ifdef Y2P_EXPERIMENTS
+#define Y2P_PHASES 16
+__device__ unsigned long long y2p_phase[1024 * 2 * Y2P_PHASES];
+extern "C" int yolo2_debug_pp_phases(void *host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(y2p_phase), sizeof(unsigned long long) * 1024 * 2 * Y2P_PHASES); }
+#define Y2P_STAMP(k) do { if (A_PHASES) { const unsigned long long t_ = wall_clock64(); ph_[k] += t_ - ph_tl; ph_tl = t_; } } while (0)
+#else
+#define Y2P_STAMP(k) do { } while (0)
+#endif
 template <bool BNBWD, int HROWS, int NSB, int SCHED>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate, int cv) {
     typedef bf16 T;
     constexpr int BM = Y2P_BM, BN = Y2P_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
     constexpr int HBYTES = HROWS * 128, HB = HBYTES + 1024, RING = 2 * HB, D = NSB - 1;
@@ -90,6 +98,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     // {kernel cycles, LOAD issue, LOAD wait, barrier after LOAD, MFMA issue, barrier after MFMA, steps, workgroup * 8 + wave}
     // (scripts/pp_phase_cycles.py: cycles per phase, and the shader clock = kernel cycles / kernel duration)
     constexpr bool A_TIME = (SCHED & 4096) != 0;
+    // +8192 (product configuration otherwise): wall-clock (100 MHz) sums per phase OUTSIDE the K loop -- prologue, loop, park, flag waits, partner reads,
+    // drain, staging, stores, final publication -- of waves 0 and 4 of every workgroup, left in y2p_phase (scripts/pp_fixed_cost.py)
+    constexpr bool A_PHASES = (SCHED & 8192) != 0;
     static_assert(!A_TIME || A_NOEPI, "the cycle stamps go where the output tile would");      // +512 no epilogue (stores, statistics), +1024 no stream-K hand-off traffic
     // halo pieces of chunk c+1 ride in the slots of taps 0 .. HSLOTS-1 of chunk c and must be covered by the wait at the end of LOAD(tap 8)
     // (ORDER 4 issues the halo piece half a step later: one slot less)
@@ -104,8 +115,18 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const long su_total = (long)MT * NT * nk;
     const int G = gridDim.x;
     const int wx = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-    long su = wx * su_total / G;
-    const long su_end = (wx + 1) * su_total / G;
+    // Cost-balanced shares (round 6).  The workgroup that holds K step 0 of a tile pays for more than K steps: it waits for and reads its partners'
+    // parked partials and runs the tile's epilogue, and when its range also holds the tail of the previous tile it pays a second prologue --
+    // measured 14 us between the first and the last workgroup to finish with equal K-step shares (profiles/r06_pp_fixed_cost.txt).  The flat space is
+    // therefore cut in VIRTUAL units: every tile is nk K steps preceded by `cv` cost units that map to no K step; workgroup w takes the w-th equal
+    // share of the virtual space, so the owner of a tile gets up to cv fewer real K steps.  cv = 0 is round 5's partition.  (launch_conv keeps
+    // cv below half a share: every workgroup of a stream-K launch holds at least one K step.)
+    const long vt = (long)nk + cv;
+    const long v_total = (long)MT * NT * vt;
+    auto v2r = [&](long v) { const long t_ = v / vt, o_ = v - t_ * vt; return t_ * nk + (o_ > cv ? o_ - cv : 0); };
+    auto share_end = [&](int w) { return G == MT * NT ? (long)(w + 1) * nk : v2r((long)(w + 1) * v_total / G); };      // (one workgroup per tile: exactly)
+    long su = wx == 0 ? 0 : share_end(wx - 1);
+    const long su_end = share_end(wx);
     // K rotation of the stream-K tiles (conv3x3_tap_kernel; profiles/r03_l2_stationary_ab.md): chunk c of tile t lives at memory chunk (c + rot_t) mod nch
     const int nch = Cp / 64;
     const double share = (double)su_total / (double)G;
@@ -116,7 +137,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(F), 0, f_bytes, 0x00020000);
     const double rcp_hw = 1.0 / (double)(H * W);
     const float rcp_w = 1.0f / (float)W;
-    unsigned char *const zero0 = smem + HBYTES;         // the zero KiB of halo buffer 0: also the sink of idle DMA slots (out-of-range DMA writes zeros)
+    unsigned char *const zero0 = smem + HBYTES;         // the zero KiB of halo buffer 0
+    // the sink of idle DMA slots (out-of-range DMA writes zeros): the zero KiB of halo buffer 1, which lies BEHIND the tile image the epilogue stages
+    // over the halo buffers -- idle slots still in flight when the K loop ends then need no drain before the staging starts (1 us per tile)
+    unsigned char *const sink = smem + HB + HBYTES;
     typedef __attribute__((address_space(3))) void *lds_void_ptr;
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
 
@@ -124,6 +148,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 #ifdef Y2P_EXPERIMENTS
   unsigned long long tm_k0 = 0, tm_issue = 0, tm_wait = 0, tm_barl = 0, tm_mfma = 0, tm_barm = 0, tm_steps = 0;
   if (A_TIME) tm_k0 = __builtin_amdgcn_s_memtime();
+  unsigned long long ph_[Y2P_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_tl = 0;
+  if (A_PHASES) { ph_tl = wall_clock64(); ph_[10] = ph_tl; }
 #endif
   for (bool first_seg = true;; first_seg = false) {
     if (su >= su_end) break;
@@ -169,7 +195,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     // one DMA slot: halo piece `hs` of chunk `hc` (or an idle write into the zero KiB) + the filter tile of K step `kb` into ring stage `bstage`
     auto issue_halo = [&](int hs, int hc, int hc_mem, bool hreal) {
         const bool real = hreal && hs * NW + wave < HPIECES;
-        unsigned char *dst = real ? smem + (hc & 1) * HB + (hs * NW + wave) * 1024 : zero0;
+        unsigned char *dst = real ? smem + (hc & 1) * HB + (hs * NW + wave) * 1024 : sink;
         const unsigned voff = real ? h_voff0 + (unsigned)hs * h_stride + (unsigned)hc_mem * 128u : Y2_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, voff, 0, 0, 0);
     };
@@ -194,13 +220,13 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 #pragma unroll
         for (int j = 0; j < HSLOTS; ++j) {
             const bool real = j * NW + wave < HPIECES;
-            unsigned char *dst = real ? smem + (c_first & 1) * HB + (j * NW + wave) * 1024 : zero0;
+            unsigned char *dst = real ? smem + (c_first & 1) * HB + (j * NW + wave) * 1024 : sink;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_first) * 128u : Y2_OOB, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < HSLOTS; ++j) {           // slots 0 .. c_tap-1 of the NEXT chunk's halo would have been issued by now
             const bool real = j < c_tap && j * NW + wave < HPIECES && (c_first + 1) * TAPS < kt_end;
-            unsigned char *dst = real ? smem + ((c_first + 1) & 1) * HB + (j * NW + wave) * 1024 : zero0;
+            unsigned char *dst = real ? smem + ((c_first + 1) & 1) * HB + (j * NW + wave) * 1024 : sink;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void_ptr)dst, 16, real ? h_voff0 + (unsigned)j * h_stride + (unsigned)mem_chunk(c_first + 1) * 128u : Y2_OOB, 0, 0, 0);
         }
         // (prologue slots always carry three instructions, filter pieces first: never fewer, never in a later position, than the counted
@@ -280,6 +306,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);
     if (wave >= 4) __builtin_amdgcn_s_barrier();         // second group: one phase behind the first
     __builtin_amdgcn_sched_barrier(0);
+    Y2P_STAMP(0);
 
     bf16x8 fa[4][TM], fb[4][TN];
     if (A_NOREAD) {
@@ -429,6 +456,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 4) __builtin_amdgcn_s_barrier();          // first group pads the barrier the second group took at the start
     __builtin_amdgcn_sched_barrier(0);
+    Y2P_STAMP(1);
+#ifdef Y2P_EXPERIMENTS
+    if (A_PHASES) ph_[9] += 1;
+#endif
 
     // Everything below indexes by (lane_e, wave_e): copies the compiler cannot see through, so that none of the hand-off / epilogue
     // address arithmetic is hoisted above the K loop (it was: 37 VGPRs of it spilled to scratch in the BN-backward variant, reloaded --
@@ -441,7 +472,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         constexpr int SLOT = BM * BN;
         const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
         const unsigned slot_lane = (unsigned)(((size_t)wave_e * (TM * TN * 16 * 64) + (size_t)lane_e * 4) * sizeof(float));
-        if (A_NOHANDOFF) { if (kt_beg > 0) continue; }
+        if (A_NOHANDOFF) { if (kt_beg > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; } }
         else if (kt_beg > 0) {
             const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
@@ -463,14 +494,23 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 // workgroup's only segment
                 park_pending = true;
             }
+            Y2P_STAMP(2);
             continue;
         }
         if (!A_NOHANDOFF && kt_end < nk) {
             const long tile_end = su - kt_end + nk;
             long covered = su;
-            for (int p = wx + 1; covered < tile_end; ++p) {
-                if (tid == 0) y2_sk_wait_and_clear(flags, p);      // (bounded: conv_shared.h)
+            // every partner's flag at once: lane i of wave 0 waits for (and clears) the flag of partner wx + 1 + i -- the flag loads are one
+            // cross-die round trip each (~1.2 us), one after the other they cost an owner with two partners 2.6 us (profiles/r06_pp_fixed_cost.txt)
+            {
+                int np_ = 0;
+                for (long cov = su; cov < tile_end; ++np_) cov = share_end(wx + 1 + np_);
+                if (wave_e == 0)
+                    for (int i = lane_e; i < np_; i += 64) y2_sk_wait_and_clear(flags, wx + 1 + i);      // (bounded: conv_shared.h)
                 __syncthreads();
+                Y2P_STAMP(3);
+            }
+            for (int p = wx + 1; covered < tile_end; ++p) {
                 const unsigned theirs = (unsigned)((size_t)p * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -484,13 +524,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                             acc[i][j][4 * q4 + 2] += v[2];
                             acc[i][j][4 * q4 + 3] += v[3];
                         }
-                covered = (long)(p + 1) * su_total / G;
+                covered = share_end(p);
+#ifdef Y2P_EXPERIMENTS
+                if (A_PHASES) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); Y2P_STAMP(4); }
+#endif
             }
         }
     }
 
     if (A_NOEPI) {       // (ablation: keep the accumulators alive, store nothing)
         if (acc[0][0][0] == 123.456f && acc[1][1][5] == 1.0f) O[0] = (bf16)acc[0][1][3];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         continue;
     }
     // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave_e LDS image, 16-byte stores), with the
@@ -501,6 +545,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave_e row) pair
         constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
         static_assert(NW * WROWS * WSTRIDE <= RING, "tile image fits the halo buffers");
+        static_assert(NW * WROWS * WSTRIDE <= HB + HBYTES, "the idle-DMA sink (zero KiB of halo buffer 1) lies behind the tile image");
         float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
         Vec16<T> yv[YG];
         const int bz_nb = min(n0 + wn_e * TN * 32 + (lane_e % WCPR) * VEC, Nf - VEC);
@@ -521,8 +566,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             bvj[j] = (bias && nokj[j]) ? bias[n] : 0.f;
             shj[j] = (stats && nokj[j]) ? bn_shift[n] : 0.f;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // idle DMA slots of the last steps have drained (they write zeros into ring stages / the zero KiB)
+        // (idle DMA slots of the last steps may still be in flight: they write zeros into ring stages and the sink KiB, all behind the tile image)
         __syncthreads();                                      // every wave has finished reading the last step's operands
+        Y2P_STAMP(5);
         unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
         const bool tail = m0 + BM > M;
         // Staging: rounded tile into this wave's LDS image (+ the statistics of the rounded values).  Two copies of the 64-element loop,
@@ -566,6 +612,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         if (act_alpha != 1.0f) { if (tail) stage_tile(std::true_type{}, std::true_type{}); else stage_tile(std::true_type{}, std::false_type{}); }
         else if (tail) stage_tile(std::false_type{}, std::true_type{});
         else stage_tile(std::false_type{}, std::false_type{});
+        Y2P_STAMP(6);
         if (bstats) {
             bz_load_y(0);
             // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
@@ -636,13 +683,26 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                 }
             }
         }
+        Y2P_STAMP(7);
+        // the idle DMA slots have landed before this workgroup's LDS is reused (next segment) or released (kernel end); the output stores ride along
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        Y2P_STAMP(12);
     }
   }
   if (park_pending) {       // the parked tail was this workgroup's last segment
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Y2P_STAMP(8);
   }
+#ifdef Y2P_EXPERIMENTS
+  if (A_PHASES && lane == 0 && (wave == 0 || wave == 4)) {
+      ph_[11] = wall_clock64();
+      unsigned long long *dst = y2p_phase + ((size_t)wx * 2 + (wave >> 2)) * Y2P_PHASES;
+#pragma unroll
+      for (int k = 0; k < Y2P_PHASES; ++k) dst[k] = ph_[k];
+  }
+#endif
 #ifdef Y2P_EXPERIMENTS
   if (A_TIME && lane == 0) {
       unsigned long long *dbg = reinterpret_cast<unsigned long long *>(O) + ((size_t)wx * NW + wave) * 8;
@@ -656,10 +716,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 // flat (tile, K step) space -- one per CU = stream-K; one per tile = whole tiles, no hand-off.
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, hipStream_t st) {
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, hipStream_t st) {
 #define Y2P_LAUNCH(BWDv, HRv, NSBv, SCv)                                                                                                    \
     conv3x3_pp_kernel<BWDv, HRv, NSBv, SCv><<<dim3(grid), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
-                                                                        H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate)
+                                                                        H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate, cv)
 #define Y2P_CASE(SCv)                                                                                              \
     case SCv:                                                                                                      \
         if (W <= 27) { if (bwd) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(false, 312, 5, SCv); }             \
@@ -676,7 +736,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
         switch (sched) {
             Y2P_ABL_CASE(2 + 64) Y2P_ABL_CASE(2 + 128) Y2P_ABL_CASE(2 + 256) Y2P_ABL_CASE(2 + 64 + 128) Y2P_ABL_CASE(2 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 256)
             Y2P_ABL_CASE(2 + 64 + 128 + 256) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 1024) Y2P_ABL_CASE(2 + 64 + 128 + 256 + 512 + 1024)
-            Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024) Y2P_ABL_CASE(2 + 512 + 4096)
+            Y2P_ABL_CASE(2 + 512) Y2P_ABL_CASE(2 + 1024) Y2P_ABL_CASE(2 + 512 + 4096) Y2P_ABL_CASE(2 + 8192) Y2P_ABL_CASE(2 + 256 + 512 + 4096) Y2P_ABL_CASE(2 + 128 + 512 + 4096) Y2P_ABL_CASE(2 + 64 + 512 + 4096)
             default: return 1;
         }
     }

@@ -52,7 +52,12 @@ struct Y2BnBwd {
 // conv_pp.hip: ping-pong tap-fused 3x3 kernel (bf16, 256 x 128 tile); returns non-zero when the image is too wide for its halo buffers
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, hipStream_t st);
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, hipStream_t st);
+
+// conv_s4.hip: the loader / consumer member of the same family (four computing waves of 128 x 64, four loader waves); same contract
+int y2_conv3x3_s4_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
+                         int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
+                         const Y2BnBwd &bz, int k_rotate, int grid, int abl, hipStream_t st);
 
 // conv_wgrad3.hip: 3x3 filter gradient with one kernel row of taps per workgroup over a padded pixel index (bf16).  variant < 0: the shape is not
 // taken (conv_wgrad.hip's per-tap kernel runs instead).

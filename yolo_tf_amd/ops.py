@@ -346,6 +346,13 @@ def set_pp(grid=-1, dmapos=-1, min_steps=-1, min_share=-1):
     _lib.load().yolo2_debug_set_pp(int(grid), int(dmapos), int(min_steps), int(min_share))
 
 
+def set_pp_cost(cv):
+    """Owner cost (K steps) of the ping-pong kernel's cost-balanced stream-K partition (yolo2_debug_set_pp_cost); 0 = equal K-step shares."""
+    lib = _lib.load()
+    if 'yolo2_debug_set_pp_cost' not in _lib.MISSING:
+        lib.yolo2_debug_set_pp_cost(int(cv))
+
+
 def check_async_errors():
     """Synchronises the current stream; raises RuntimeError when a stream-K tile owner gave up waiting for a partner (include/yolo2_hip.h
     yolo2_check_async_errors): errors surface, the device never hangs."""
