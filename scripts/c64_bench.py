@@ -1,0 +1,51 @@
+"""conv2 / conv4 forward (64 -> 128 channels, 104 x 104): conv_c64.hip against the generic per-tap kernel, per epilogue, at batch 16 and 64 (a
+per-workgroup fixed cost -- the filter load into registers -- shows as a time that does not scale with the batch).  Run in ONE process per library
+switch: YOLO2_C64=0 / 1 python scripts/c64_bench.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_tf_amd import ops
+T = torch.bfloat16
+H, cin, cout = 104, 64, 128
+ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(n):
+                fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); g.replay(); b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / n * 1e3)
+    return best
+
+
+for B in [int(b) for b in os.environ.get("BATCHES", "16,64").split(",")]:
+    M = B * H * H
+    x = torch.randn(M * cin, device='cuda').to(T)
+    y = torch.zeros(M * cout, dtype=T, device='cuda')
+    w = torch.randn(9 * cin * cout, device='cuda') * 0.05
+    F = torch.zeros(cout * 9 * cin, dtype=T, device='cuda')
+    ops.filter_prep(w, F, None, 3, cin, cin, cout, cout, T)
+    part = torch.zeros(2 * 256 * cout, dtype=torch.float32, device='cuda')
+    shift = torch.zeros(cout, device='cuda')
+    bias = torch.zeros(cout, device='cuda')
+    res = []
+    for name, fn in (('plain', lambda: ops.conv2d_ws(x, F, None, y, ws, B, H, H, cin, cin, cout, cout, 3)),
+                     ('stats', lambda: ops.conv2d_bn(x, F, y, ws, B, H, H, cin, cin, cout, cout, 3, shift, part)),
+                     ('bias+leaky', lambda: ops.conv2d_bias_leaky(x, F, bias, y, ws, B, H, H, cin, cin, cout, cout, 3, 0.1))):
+        t = timed(fn)
+        res.append('%s %.1f us (%.0f TFLOP/s)' % (name, t, 2.0 * M * cout * 9 * cin / t * 1e-6))
+        plan = ops.last_conv_plan()
+    print('YOLO2_C64=%s batch %d: %s   plan %s' % (os.environ.get('YOLO2_C64', '1'), B, ', '.join(res), '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))

@@ -22,5 +22,5 @@ for w in $WHAT; do
     *) echo "unknown kernel '$w' (pp, w3, c32, s4)"; exit 1 ;;
   esac
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libyolo2hip_exp.so conv_igemm.o $PP $S4 conv_wgrad.o $W3 $C32 conv_first.o elementwise.o head.o yolo1.o nms.o augment.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libyolo2hip_exp.so conv_igemm.o $PP $S4 conv_wgrad.o $W3 $C32 conv_c64.o conv_first.o elementwise.o head.o yolo1.o nms.o augment.o || exit 1
 ls -la libyolo2hip_exp.so

@@ -120,6 +120,9 @@ CONV_SHAPES = [
     (1, 7, 9, 32, 64, 3),       # ... one partial tile, odd extents
     (3, 40, 33, 32, 64, 3),     # ... more tiles than one workgroup round leaves whole
     (2, 9, 11, 320, 200, 3),    # five chunks; data gradient single-chunk (ldy = 200)
+    (2, 12, 20, 64, 128, 3),    # 64 -> 128 channels: the persistent conv2 / conv4 kernel with the filter in registers (conv_c64.hip)
+    (1, 7, 9, 64, 128, 3),      # ... one partial tile, odd extents
+    (3, 40, 33, 64, 128, 3),    # ... more tiles than one workgroup round leaves whole
 ]
 
 
@@ -273,6 +276,60 @@ def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
     assert_close(host(yb).reshape(B, H, W, Cout), ref, BF16_RTOL, 'c32 fwd (bn) %s wgs %d' % (shape, wgs))
     z = ref + bias
     assert_close(host(yl).reshape(B, H, W, Cout), np.maximum(z, np.float32(0.1) * z), BF16_RTOL, 'c32 fwd + bias + leaky %s wgs %d' % (shape, wgs))
+    y64 = host(yb).astype(np.float64).reshape(M, Cout)
+    assert np.abs(host(mean) - y64.mean(0)).max() <= 2e-5 * np.sqrt(y64.var(0)).max() + 1e-6
+    assert np.abs(host(var) - y64.var(0)).max() <= 1e-4 * y64.var(0).max()
+    assert float(part.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('wgs,shape,c64', [(3, (3, 40, 33, 64, 128, 3), True),     # 16 tiles on 3 workgroups: several tiles each, both halo buffers reused
+                                            (2, (2, 12, 20, 64, 128, 3), True),      # 3 tiles on 2 workgroups
+                                            (0, (2, 26, 27, 64, 128, 3), True),      # the product grid (one workgroup per tile here)
+                                            (0, (1, 4, 320, 64, 128, 3), False)])    # a 320-wide row: two halo buffers do not fit LDS -> the generic kernel
+def test_conv_c64_persistent_tiles_and_width_fallback(ops, wgs, shape, c64):
+    """conv_c64.hip (conv2 / conv4 forward: filter in registers, persistent workgroups over 256-position tiles of the padded index).  With the
+    workgroup count forced down every workgroup takes several tiles (double-buffered halo, per-lane statistics carried across tiles).  Output,
+    bias + leaky and the fused batch-norm sums against the oracle; the plan word says which kernel ran."""
+    B, H, W, Cin, Cout, k = shape
+    rng = np.random.RandomState(sum(shape) + 13)
+    x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
+    w = bf16_round((rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cin)).astype(np.float32) + 0.02)
+    bias = rng.randn(Cout).astype(np.float32)
+    T = torch.bfloat16
+    M = B * H * W
+    F = torch.zeros(Cout * k * k * Cin, dtype=T, device='cuda')
+    ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, Cout, T)
+    xd = dev(x, T)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    ref = R.conv2d(x, w)
+    try:
+        if wgs:
+            ops.set_stream_workgroups(wgs)
+        y = torch.zeros(M * Cout, dtype=T, device='cuda')
+        ops.conv2d_ws(xd, F, None, y, ws, B, H, W, Cin, Cin, Cout, Cout, k)
+        plan = ops.last_conv_plan()
+        assert ((plan['BM'], plan['BN'], plan['stages']) == (256, 128, 9)) == c64, plan
+        yl = torch.zeros(M * Cout, dtype=T, device='cuda')
+        ops.conv2d_bias_leaky(xd, F, dev(bias), yl, ws, B, H, W, Cin, Cin, Cout, Cout, k, 0.1)      # the inference epilogue (folded BN): bias, leaky_relu
+        yb = torch.zeros(M * Cout, dtype=T, device='cuda')
+        part = torch.zeros(2 * 256 * Cout, dtype=torch.float32, device='cuda')
+        shift = dev((rng.randn(Cout) * 0.1).astype(np.float32))
+        mean, var = torch.zeros(Cout, device='cuda'), torch.zeros(Cout, device='cuda')
+        ops.conv2d_bn(xd, F, yb, ws, B, H, W, Cin, Cin, Cout, Cout, k, shift, part)
+        planb = ops.last_conv_plan()
+        assert ((planb['BM'], planb['BN'], planb['stages']) == (256, 128, 9)) == c64, planb
+        ops.bn_finalize(part, shift, M, Cout, mean, var, None, None, 0.999)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_stream_workgroups(0)
+    assert_close(host(y).reshape(B, H, W, Cout), ref, BF16_RTOL, 'c64 fwd %s wgs %d' % (shape, wgs))
+    assert_close(host(yb).reshape(B, H, W, Cout), ref, BF16_RTOL, 'c64 fwd (bn) %s wgs %d' % (shape, wgs))
+    assert torch.equal(y, yb)                     # the statistics epilogue does not change what is stored
+    z = ref + bias
+    assert_close(host(yl).reshape(B, H, W, Cout), np.maximum(z, np.float32(0.1) * z), BF16_RTOL, 'c64 fwd + bias + leaky %s wgs %d' % (shape, wgs))
+    # per element against the oracle on the bf16-rounded operands: one bf16 ulp of the stored output
+    got = host(y).reshape(B, H, W, Cout).astype(np.float64)
+    assert (np.abs(got - ref) <= 4e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all()
     y64 = host(yb).astype(np.float64).reshape(M, Cout)
     assert np.abs(host(mean) - y64.mean(0)).max() <= 2e-5 * np.sqrt(y64.var(0)).max() + 1e-6
     assert np.abs(host(var) - y64.var(0)).max() <= 1e-4 * y64.var(0).max()
@@ -612,12 +669,13 @@ def test_conv_wgrad_border_only_inputs(ops, shape, mode, which):
 
 
 @pytest.mark.parametrize('which', BORDERS)
+@pytest.mark.parametrize('chan', [(32, 64, 512, 64), (64, 128, 256, 128)], ids=['c32', 'c64'])      # (Cin, Cout, plan BM, plan BN): conv_c32.hip / conv_c64.hip
 @pytest.mark.parametrize('shape', [(2, 12, 20), (1, 7, 9), (3, 40, 33), (2, 31, 16)])
-def test_conv_c32_border_only_inputs(ops, shape, which):
+def test_conv_c32_border_only_inputs(ops, shape, which, chan):
     """conv_c32.hip (conv1 forward, padded position index with one zero column per row and one zero row per image): an input that is non-zero
     only on the image border, against the oracle; every output element further than one pixel from the border must be EXACTLY zero."""
     B, H, W = shape
-    Cin, Cout, k = 32, 64, 3
+    Cin, Cout, k = chan[0], chan[1], 3
     rng = np.random.RandomState(sum(shape) + len(which))
     mask = _border_mask(H, W, which)
     x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32)) * mask[None, :, :, None]
@@ -630,7 +688,7 @@ def test_conv_c32_border_only_inputs(ops, shape, which):
     ops.conv2d_ws(dev(x, T), F, None, y, ws, B, H, W, Cin, Cin, Cout, Cout, k)
     plan = ops.last_conv_plan()
     torch.cuda.synchronize()
-    assert (plan['BM'], plan['BN'], plan['stages']) == (512, 64, 9), plan
+    assert (plan['BM'], plan['BN'], plan['stages']) == (chan[2], chan[3], 9), plan
     got = host(y).reshape(B, H, W, Cout)
     ref = R.conv2d(x.astype(np.float64), w.astype(np.float64))
     scale = np.abs(ref).max()

@@ -595,6 +595,10 @@ static unsigned *g_flag_pool[64] = {nullptr};
 static unsigned g_flag_counter[64] = {0};
 static std::atomic<unsigned> g_sk_wait_ticks{0};       // 0 = Y2_SK_DEFAULT_WAIT_TICKS (tests shorten it: yolo2_debug_set_streamk_wait_us)
 static std::atomic<int> g_sk_unclamped{0};             // tests only: lets a forced grid exceed the number of K steps (the partition bug the wait bound exists for)
+__global__ void async_error_gather_kernel(const unsigned *__restrict__ pool, unsigned *__restrict__ host_words) {
+    if (threadIdx.x < Y2_STREAM_FLAG_SETS)
+        host_words[threadIdx.x] = __hip_atomic_load(pool + (size_t)threadIdx.x * Y2_STREAM_FLAG_STRIDE + Y2_STREAM_FLAG_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // the current device's pool, created on first use (caller holds g_flag_mutex); does NOT advance the rotating set counter
 static unsigned *ensure_pool_locked(int dev) {
     if (!g_flag_pool[dev]) {
@@ -631,11 +635,10 @@ extern "C" int yolo2_async_error_snapshot(unsigned *host_words, void *stream) {
         return YOLO2_OK;
     }
     static_assert(YOLO2_ASYNC_ERROR_WORDS == Y2_STREAM_FLAG_SETS, "one status word per flag set");
-    if (hipMemcpy2DAsync(host_words, sizeof(unsigned), pool + Y2_STREAM_FLAG_WORDS, Y2_STREAM_FLAG_STRIDE * sizeof(unsigned), sizeof(unsigned),
-                         Y2_STREAM_FLAG_SETS, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
-        yolo2_set_error("yolo2_async_error_snapshot: HIP error: %s", hipGetErrorString(hipGetLastError()));
-        return YOLO2_E_LAUNCH;
-    }
+    // one eight-lane kernel writing straight into the pinned (device-mapped) host words: a strided 2-D copy of eight words goes through the runtime's
+    // staging path and costs tens of microseconds of stream time (measured: +0.4 % on the training step when enqueued every eighth step)
+    async_error_gather_kernel<<<1, 64, 0, (hipStream_t)stream>>>(pool, host_words);
+    Y2_CHECK_LAUNCH();
     return YOLO2_OK;
 }
 // Synchronises `stream` and reports what only the device can know: a stream-K owner that gave up waiting for a partner's partial tile
@@ -1022,6 +1025,18 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         int rows = 0;
         if (y2_c32_fwd(P, F, O, B, H, W, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
             const int plan_[8] = {512, 64, 8, 8, 9, 0, rows, 1};
+            for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
+            if (bn_part) g_last_stat_rows = rows;
+            Y2_CHECK_LAUNCH();
+            return YOLO2_OK;
+        }
+    }
+    static const bool c64_direct = y2_env_int("YOLO2_C64", 1) != 0;
+    if (c64_direct && !bwd && y2_c64_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)F & 15) == 0) {      // 64 -> 128 channels (conv2 / conv4): filters in registers (conv_c64.hip)
+        const Tune tu = tune_now();
+        int rows = 0;
+        if (y2_c64_fwd(P, F, O, B, H, W, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
+            const int plan_[8] = {256, 128, 8, 8, 9, 0, rows, 1};
             for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
             if (bn_part) g_last_stat_rows = rows;
             Y2_CHECK_LAUNCH();

@@ -71,3 +71,9 @@ void y2_magic_u32(unsigned d, unsigned *m, unsigned *s);
 bool y2_c32_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
 int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st);
+
+// conv_c64.hip: persistent 3x3 forward for 64-channel inputs and 128 filters (Darknet-19 conv2 / conv4), bf16, filters held in registers.  y2_c64_fwd
+// returns non-zero when the image is too wide for its LDS plan (the caller then takes the generic kernels).
+bool y2_c64_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
+int y2_c64_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
+               int cus, int *rows, hipStream_t st);
