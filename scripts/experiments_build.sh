@@ -12,15 +12,16 @@ cd "$(dirname "$0")/../yolo_tf_amd/csrc" || exit 1
 python build.py > /dev/null || exit 1          # the product objects, up to date
 WHAT="${*:-pp w3 c32 s4}"
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result"
-PP=conv_pp.o; W3=conv_wgrad3.o; C32=conv_c32.o; S4=conv_s4.o
+PP=conv_pp.o; W3=conv_wgrad3.o; C32=conv_c32.o; S4=conv_s4.o; D1=conv_d1.o
 for w in $WHAT; do
   case $w in
     pp)  $HIPCC -DY2P_EXPERIMENTS -c conv_pp.hip -o conv_pp_exp.o || exit 1; PP=conv_pp_exp.o ;;
     w3)  $HIPCC -DY2W3_EXPERIMENTS -c conv_wgrad3.hip -o conv_wgrad3_exp.o || exit 1; W3=conv_wgrad3_exp.o ;;
     c32) $HIPCC -DY2C32_EXPERIMENTS -c conv_c32.hip -o conv_c32_exp.o || exit 1; C32=conv_c32_exp.o ;;
     s4)  $HIPCC -DY2S_EXPERIMENTS -c conv_s4.hip -o conv_s4_exp.o || exit 1; S4=conv_s4_exp.o ;;
-    *) echo "unknown kernel '$w' (pp, w3, c32, s4)"; exit 1 ;;
+    d1)  $HIPCC -DY2D1_EXPERIMENTS -c conv_d1.hip -o conv_d1_exp.o || exit 1; D1=conv_d1_exp.o ;;
+    *) echo "unknown kernel '$w' (pp, w3, c32, s4, d1)"; exit 1 ;;
   esac
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libyolo2hip_exp.so conv_igemm.o $PP $S4 conv_wgrad.o $W3 $C32 conv_c64.o conv_first.o elementwise.o head.o yolo1.o nms.o augment.o || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libyolo2hip_exp.so conv_igemm.o $PP $S4 conv_wgrad.o $W3 $C32 conv_c64.o $D1 conv_first.o elementwise.o head.o yolo1.o nms.o augment.o || exit 1
 ls -la libyolo2hip_exp.so

@@ -17,6 +17,8 @@ from prof_summary import load          # noqa: E402
 def dominant(name):
     if 'conv3x3_pp_kernel' in name or 'conv3x3_tap_kernel' in name:       # (round 4: ping-pong tap-fused kernel; rounds 2-3: conv3x3_tap_kernel)
         return True
+    if 'conv_c64_fwd_kernel' in name or 'conv3x3_s4_kernel' in name:        # (round 6: conv2 / conv4 forward with the filter in registers; the loader / consumer member)
+        return True
     m = re.search(r'conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)      # T, BN, WGN, NSTAGE, KS
     if m:
         return int(m.group(2)) == 128 and int(m.group(5)) == 3
@@ -36,7 +38,7 @@ def main():
           % (len(dom) / steps, tot / len(dom) / 1e3, tot / steps / 1e3, 100.0 * tot / sum(e - s for _, s, e in sel)))
     by = {}
     for n, d in dom:
-        k = 'conv3x3_pp_kernel' if 'conv3x3_pp' in n else 'conv3x3_tap_kernel' if 'conv3x3_tap' in n else re.sub(r'EEv.*', '', n.replace('_Z17', ''))[:70]
+        k = 'conv3x3_pp_kernel' if 'conv3x3_pp' in n else 'conv_c64_fwd_kernel' if 'conv_c64' in n else 'conv3x3_s4_kernel' if 'conv3x3_s4' in n else 'conv3x3_tap_kernel' if 'conv3x3_tap' in n else re.sub(r'EEv.*', '', n.replace('_Z17', ''))[:70]
         a = by.setdefault(k, [0, 0])
         a[0] += 1
         a[1] += d

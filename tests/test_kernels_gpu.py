@@ -508,7 +508,10 @@ def test_streamk_unserviceable_grid_surfaces_as_error(ops):
                                          ((4, 52, 52, 256, 128, 3), True),     # full grid, wide rows
                                          ((2, 26, 26, 512, 256, 1), True),
                                          ((3, 20, 20, 64, 32, 3), True),       # 32-wide filter tile
-                                         ((2, 13, 13, 512, 256, 3), False)])   # K-sliced grid -> two-step form inside the call
+                                         ((2, 13, 13, 512, 256, 3), False),   # K-sliced grid -> two-step form inside the call
+                                         ((2, 104, 104, 64, 128, 1), True),    # conv3's data gradient: the persistent 1x1 kernel (conv_d1.hip, bf16), 64-channel reduction
+                                         ((4, 52, 52, 128, 256, 1), True),     # conv6's: 128-channel reduction, two column groups
+                                         ((3, 53, 55, 64, 384, 1), True)])     # ragged last tile, three column groups, more tiles than workgroups leave whole
 def test_conv_dgrad_bn_fused_sums(ops, shape, fused, mode):
     """yolo2_conv2d_dgrad_bn == yolo2_conv2d_ws followed by yolo2_bn_leaky_bwd_reduce: the same dX bit for bit, dgamma / dbeta equal up
     to the f32 summation order; the partial rows are zero again afterwards."""
@@ -536,6 +539,8 @@ def test_conv_dgrad_bn_fused_sums(ops, shape, fused, mode):
     pending = ops.conv2d_dgrad_bn(dy, F, dx, ws, B, H, W, ldy, ldy, Cin, ldx, k, yprev, mean, var, gamma, beta, dg, db, part, red, 1e-3, 0.1)
     plan = ops.last_conv_plan()
     assert pending == bool(plan['split'] & 0x100), (pending, plan)
+    if mode == 'bf16' and k == 1 and Cout in (64, 128) and Cin % 128 == 0 and M >= 8192 and os.environ.get('YOLO2_D1', '1') != '0':
+        assert (plan['BM'], plan['stages'], plan['grid_y']) == (128, 1, Cin // 128) and plan['grid_x'] <= 32, plan      # conv_d1.hip: persistent, 32 partial rows
     if mode == 'bf16':                     # (f32 tiles of some variants do not fit the LDS image: those run the two-step form)
         assert pending == (fused and os.environ.get('YOLO2_FUSE_BN_BWD', '1') != '0'), (pending, plan)
     if pending:

@@ -16,6 +16,7 @@ SOURCES = {
     'conv_wgrad3.hip': [],
     'conv_c32.hip': [],
     'conv_c64.hip': [],
+    'conv_d1.hip': [],
     'conv_first.hip': [],
     'elementwise.hip': [],
     'head.hip': ['-ffp-contract=off'],

@@ -1046,7 +1046,21 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     bool stats_done = true;
     if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
         static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;
+        static const bool d1_direct = y2_env_int("YOLO2_D1", 1) != 0;
         const bool can = fuse && Nf % vec == 0;
+        if (can && d1_direct && bn_part && y2_d1_shape(Cp, ldp, Nf, ldo, ksize, dtype, (long)B * H * W) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)bwd->Y & 15) == 0) {
+            // 1x1 data gradient of the wide early stages (conv3 / conv6): persistent kernel with prefetched y vectors and launch-long sums (conv_d1.hip)
+            const Tune tu = tune_now();
+            int rows = 0;
+            if (y2_d1_dgrad_bn(P, F, O, (long)B * H * W, Cp, Nf, bn_part, *bwd, tu.cus, &rows, (hipStream_t)stream) == 0) {
+                const int plan_[8] = {128, 128, 8, Cp / 8, 1, 0x100, rows, Nf / 128};
+                for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
+                g_last_stat_rows = rows;
+                Y2_CHECK_LAUNCH();
+                if (pending) *pending = 1;
+                return pending ? YOLO2_OK : y2_bn_part_to_grads(bn_part, Nf, dgamma, dbeta, (hipStream_t)stream);
+            }
+        }
         if (can) {
             Y2_DISPATCH_DTYPE(dtype, rc = launch_conv<T>(P, F, bias, O, ws, ws_bytes, B, H, W, Cp, ldp, Nf, ldo, ksize, (hipStream_t)stream,
                                                          nullptr, bn_part, &stats_done, act_alpha, *bwd));

@@ -77,3 +77,7 @@ int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const
 bool y2_c64_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
 int y2_c64_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st);
+
+// conv_d1.hip: persistent 1x1 data gradient + the producer layer's BN / leaky backward sums for the wide early stages (conv3 / conv6), bf16
+bool y2_d1_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, long M);
+int y2_d1_dgrad_bn(const void *P, const void *F, void *O, long M, int Cp, int Nf, float *bn_part, const Y2BnBwd &bz, int cus, int *rows, hipStream_t st);
