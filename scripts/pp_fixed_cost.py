@@ -44,7 +44,13 @@ for name, H, cin, cout in LAYERS:
     ops.filter_prep(w, Ff, None, 3, cin, cin, cout, cout, T)
     part = torch.zeros(2 * 256 * cout, dtype=torch.float32, device='cuda')
     shift = torch.zeros(cout, device='cuda')
-    fn = (lambda: ops.conv2d_ws(x, Ff, None, y, ws, B, H, H, cin, cin, cout, cout, 3)) if DGRAD else \
+    BN = os.environ.get('BN', '0') == '1'      # DGRAD=1 BN=1: the data gradient with the producer's BN-backward sums in its epilogue
+    yprev = torch.randn(M * cout, device='cuda').to(T)
+    mean_, var_ = torch.zeros(cout, device='cuda'), torch.ones(cout, device='cuda')
+    dg, db = torch.zeros(cout, device='cuda'), torch.zeros(cout, device='cuda')
+    red = torch.zeros(ops.workspace_bytes('bn', cout) // 8, dtype=torch.float64, device='cuda')
+    fn = (lambda: ops.conv2d_dgrad_bn(x, Ff, y, ws, B, H, H, cin, cin, cout, cout, 3, yprev, mean_, var_, mean_ + 1, mean_, dg, db, part, red, 1e-5, 0.1)) if (DGRAD and BN) else \
+         (lambda: ops.conv2d_ws(x, Ff, None, y, ws, B, H, H, cin, cin, cout, cout, 3)) if DGRAD else \
          (lambda: ops.conv2d_bn(x, Ff, y, ws, B, H, H, cin, cin, cout, cout, 3, shift, part))
     S4 = os.environ.get('S4', '0') == '1'      # the loader / consumer kernel (conv_s4.hip; experiments build with s4)
     ops.set_igemm_tap(3 if S4 else 2)

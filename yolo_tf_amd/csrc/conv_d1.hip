@@ -163,7 +163,23 @@ __global__ __launch_bounds__(512) void conv_d1_dgrad_bn_kernel(
             ps[0][k] += __shfl_xor(ps[0][k], off, 64);
             ps[1][k] += __shfl_xor(ps[1][k], off, 64);
         }
-    if (lane < WCPR && T_ > 0) {
+    // ... and the four wave rows of the workgroup (the same channels per column half) in LDS: a quarter of the atomic adds
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                       // every wave is done with the operand buffers
+    float *const red = reinterpret_cast<float *>(ab);
+    if (lane < WCPR) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) { red[(wave * WCPR + lane) * 2 * VEC + k] = ps[0][k]; red[(wave * WCPR + lane) * 2 * VEC + VEC + k] = ps[1][k]; }
+    }
+    __syncthreads();
+    if (wm == 0 && lane < WCPR) {
+#pragma unroll
+        for (int r = 1; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                ps[0][k] += red[((2 * r + wn) * WCPR + lane) * 2 * VEC + k];
+                ps[1][k] += red[((2 * r + wn) * WCPR + lane) * 2 * VEC + VEC + k];
+            }
         const int slot = (int)(blockIdx.x & (D1_STAT_ROWS - 1));
         float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll

@@ -538,9 +538,34 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
                     ps[0][k] += __shfl_xor(ps[0][k], off, 64);
                     ps[1][k] += __shfl_xor(ps[1][k], off, 64);
                 }
+            // The WGM wave rows of the tile hold sums of the SAME channels.  Where the LDS plan leaves room behind the tile image they meet there and the
+            // tile leaves ONE partial row per filter (the host counts rows per pixel tile then: y2_bnbwd_rows_per_tile) -- a WGM-th of the adds and of
+            // the (tile, wave row) pairs competing for the partial rows: same-address f32 atomics serialise at ~0.1 us each
+            constexpr bool RED = BNBWD && WGM > 1 && NW * WROWS * WSTRIDE + NW * WCPR * 2 * VEC * 4 <= NSTAGE * STAGE;
             const int nb = n0 + wn * TN * 32 + lane * VEC;
-            if (lane < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+            bool writer = lane < WCPR && nb < Nf;
+            int row_id = mt * WGM + wm;
+            if constexpr (RED) {
+                float *const red = reinterpret_cast<float *>(smem + NW * WROWS * WSTRIDE);
+                if (lane < WCPR) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) { red[(wave * WCPR + lane) * 2 * VEC + k] = ps[0][k]; red[(wave * WCPR + lane) * 2 * VEC + VEC + k] = ps[1][k]; }
+                }
+                __syncthreads();
+                writer = writer && wm == 0;
+                row_id = mt;
+                if (writer) {
+#pragma unroll
+                    for (int r = 1; r < WGM; ++r)
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            ps[0][k] += red[((r * WGN + wn) * WCPR + lane) * 2 * VEC + k];
+                            ps[1][k] += red[((r * WGN + wn) * WCPR + lane) * 2 * VEC + VEC + k];
+                        }
+                }
+            }
+            if (writer) {
+                const int slot = row_id & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                 float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -729,8 +754,9 @@ static int y2_stat_rows_limit(int Nf, int vec) {
 }
 static int y2_stat_rows(long wave_rows, int limit) {
     if (wave_rows <= limit) return (int)wave_rows;         // one row per (pixel tile, wave row): plain stores
+    // (<= ~16 adds per address: same-address f32 atomics serialise at ~0.1 us each -- 42 per address cost the 52 x 52 BN-backward launch 12 us)
     int r = 16;
-    while (r < 128 && (long)r * 128 < wave_rows) r <<= 1;
+    while (r < 128 && (long)r * 16 < wave_rows) r <<= 1;
     while (r > limit) r >>= 1;
     return r;
 }
@@ -750,7 +776,8 @@ extern "C" int yolo2_last_bn_part_rows(void) { return g_last_stat_rows; }
         const dim3 g_ = (gridv);                                                                                   \
         const int plan_[8] = {BMv, BNv, NWv, CHv, NSv, SPLITv, (int)g_.x, (int)g_.y};                              \
         for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];                                                \
-        const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)cdiv(M, BMv) * (NWv / WGNv), Nf, VEC);                     \
+        const bool fusedbw_ = bz.Y && SPLITv != 1 && !CTv && wide_store && igemm_wide_fits<T, BMv, BNv, WGNv, NSv, CHv, NWv>();                      \
+        const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)cdiv(M, BMv) * (fusedbw_ ? y2_bnbwd_rows_per_tile<T, BMv, BNv, WGNv, NSv, CHv, NWv>() : (NWv / WGNv)), Nf, VEC); \
         if (!bz.Y)                                                                                                 \
             conv_igemm_kernel<T, BNv, WGNv, NSv, KSv, SPLITv, CTv, CHv, NWv, BMv, false><<<g_, NWv * 64, 0, st>>>(  \
                 Y2_IGEMM_ARGS, bn_part, sk_flags, act_alpha, wide_store, bz_);                                     \
@@ -781,6 +808,14 @@ extern "C" int yolo2_last_bn_part_rows(void) { return g_last_stat_rows; }
         else Y2_IGEMM(128, 2, 3, 1, SPLITv, false, 8, 8, gridv);                       \
     } while (0)
 
+// partial rows one tile of a BN-backward instantiation writes: 1 when its wave rows meet in LDS (mirror of RED in the kernel), else one per wave row
+template <typename T, int BMv, int BN, int WGN, int NSTAGE, int CH, int NW>
+static constexpr int y2_bnbwd_rows_per_tile() {
+    constexpr int RPI = 64 / CH, ROWB = CH * 16, WGM = NW / WGN, TM = BMv / WGM / 32, TN = BN / WGN / 32, VEC = 16 / (int)sizeof(T);
+    constexpr int B_IT = (BN / RPI + NW - 1) / NW, STAGE = (BMv + B_IT * NW * RPI) * ROWB;
+    constexpr int WROWS = TM * 32, WROWB = TN * 32 * (int)sizeof(T), WSTRIDE = WROWB + 16, WCPR = WROWB / 16;
+    return (WGM > 1 && NW * WROWS * WSTRIDE + NW * WCPR * 2 * VEC * 4 <= NSTAGE * STAGE) ? 1 : WGM;
+}
 // does this instantiation have the LDS-transposed (wide-store) epilogue?  (mirror of WIDE_FITS in the kernel)
 template <typename T, int BMv, int BN, int WGN, int NSTAGE, int CH, int NW>
 static constexpr bool igemm_wide_fits() {
@@ -909,7 +944,9 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
-                const Y2BnBwd bz_ = y2_with_stat_rows(bz, (long)MT2 * 4, Nf, VEC);
+                // partial rows: forward statistics one per (pixel tile, wave row); BN-backward sums of the ping-pong kernel one per pixel tile (its wave
+                // rows meet in LDS); the loader / consumer kernel one per (pixel tile, 64-row group)
+                const Y2BnBwd bz_ = y2_with_stat_rows(bz, (bz.Y && tap_mode != 3) ? (long)MT2 : (long)MT2 * 4, Nf, VEC);
                 // owner cost of the cost-balanced partition: below half a workgroup's share, so that every workgroup keeps real K steps (an owner
                 // waits for the flag of every workgroup inside its tile); whole-tile grids have no shares to balance
                 int cv = grid == tiles_t ? 0 : g_pp_cv.load(std::memory_order_relaxed);
@@ -1047,7 +1084,10 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
         static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;
         static const bool d1_direct = y2_env_int("YOLO2_D1", 1) != 0;
-        const bool can = fuse && Nf % vec == 0;
+        // (A/B: YOLO2_FUSE_BN_BWD_NARROW=1 fuses them again; the default sends the 3x3 data gradients with <= 64 filters on >= 100k pixels -- conv4's at batch 16: its fused epilogue
+        // costs the per-tap kernel 32 us, the separate reduction 19 -- to the two-kernel form)
+        static const bool fuse_narrow = y2_env_int("YOLO2_FUSE_BN_BWD_NARROW", 0) != 0;
+        const bool can = fuse && Nf % vec == 0 && (fuse_narrow || !(ksize == 3 && Nf <= 64 && (long)B * H * W >= 100000));
         if (can && d1_direct && bn_part && y2_d1_shape(Cp, ldp, Nf, ldo, ksize, dtype, (long)B * H * W) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)bwd->Y & 15) == 0) {
             // 1x1 data gradient of the wide early stages (conv3 / conv6): persistent kernel with prefetched y vectors and launch-long sums (conv_d1.hip)
             const Tune tu = tune_now();

@@ -672,9 +672,26 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
                     ps[0][k] += __shfl_xor(ps[0][k], off, 64);
                     ps[1][k] += __shfl_xor(ps[1][k], off, 64);
                 }
+            // The four wave rows of the tile hold sums of the SAME channels: they meet in LDS (the 7 KiB between the tile image and the idle-DMA sink) and
+            // the tile leaves ONE partial row per filter -- a quarter of the adds, and at most 169 pixel tiles instead of 676 (tile, wave row) pairs
+            // competing for the partial rows: same-address f32 atomics were 12 us of the 52 x 52 launch's 52 (profiles/r06_pp_bn_epilogue.txt)
+            static_assert(NW * WROWS * WSTRIDE + NW * WCPR * 2 * VEC * 4 <= HB + HBYTES, "reduction scratch fits between the tile image and the sink");
+            float *const red = reinterpret_cast<float *>(smem + NW * WROWS * WSTRIDE);
+            if (lane_e < WCPR) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { red[(wave_e * WCPR + lane_e) * 2 * VEC + k] = ps[0][k]; red[(wave_e * WCPR + lane_e) * 2 * VEC + VEC + k] = ps[1][k]; }
+            }
+            __syncthreads();
             const int nb = n0 + wn_e * TN * 32 + lane_e * VEC;
-            if (lane_e < WCPR && nb < Nf) {
-                const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+            if (wm_e == 0 && lane_e < WCPR && nb < Nf) {
+#pragma unroll
+                for (int r = 1; r < WGM; ++r)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        ps[0][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + k];
+                        ps[1][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + VEC + k];
+                    }
+                const int slot = mt & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
                 float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
 #pragma unroll
                 for (int k = 0; k < VEC; ++k) {
@@ -730,6 +747,7 @@ int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigne
 #ifdef Y2P_EXPERIMENTS      // (scripts/pp_experiments_build.sh: the SCHED variants and timing ablations behind profiles/r04_pp*.txt)
 #define Y2P_ABL_CASE(SCv)                                                                                          \
     case SCv:                                                                                                      \
+        if (SCv == 2 + 8192 && bwd) { if (W <= 27) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(true, 368, 4, SCv); return 0; }      \
         if (W <= 27) Y2P_LAUNCH(false, 312, 5, SCv); else Y2P_LAUNCH(false, 368, 4, SCv);                          \
         return 0;
     if (sched >= 64) {
