@@ -567,6 +567,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             shj[j] = (stats && nokj[j]) ? bn_shift[n] : 0.f;
         }
         // (idle DMA slots of the last steps may still be in flight: they write zeros into ring stages and the sink KiB, all behind the tile image)
+        if (BNBWD && bstats) bz_load_y(0);                    // (in flight under the staging loop)
         __syncthreads();                                      // every wave has finished reading the last step's operands
         Y2P_STAMP(5);
         unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
@@ -614,7 +615,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         else stage_tile(std::false_type{}, std::false_type{});
         Y2P_STAMP(6);
         if (bstats) {
-            bz_load_y(0);
             // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
             // loop, where the 64 accumulator registers are still live -- the BN-backward instantiations then need 245 .. 256+ registers)
             int nb_c = bz_nb;
