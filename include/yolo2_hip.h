@@ -163,6 +163,10 @@ int yolo2_conv2d_dgrad_bn(const void *dY, const void *F, void *dX, float *ws, si
                           int Nf, int ldo, int ksize, const void *Yprev, const float *mean, const float *var, const float *gamma,
                           const float *beta, float *dgamma, float *dbeta, float *bn_part, double *red_ws, float eps, float alpha,
                           int *pending, int dtype, void *stream);
+/* 1 when yolo2_conv2d_dgrad_bn would take the sums from its epilogue for a data gradient with Nf output channels on B x H x W pixels, 0 when the launch
+ * rule prefers a plain data gradient there (3x3, <= 64 channels, >= 100k pixels: the reduction then costs less as its own pass): a host that asks first
+ * calls yolo2_conv2d_ws + yolo2_bn_leaky_bwd_reduce_part + yolo2_bn_leaky_bwd_apply_fin for such a layer (engine.Engine._bind does) */
+int yolo2_conv2d_dgrad_bn_fuses(int B, int H, int W, int Nf, int ksize, int dtype);
 /* column sums of the partial rows left by yolo2_conv2d_dgrad_bn: plane 0 -> dgamma, plane 1 -> dbeta; rows zeroed again */
 int yolo2_bn_part_to_grads(float *bn_part, int C, float *dgamma, float *dbeta, void *stream);
 

@@ -1,6 +1,6 @@
-"""conv2 / conv4 forward (64 -> 128 channels, 104 x 104): conv_c64.hip against the generic per-tap kernel, per epilogue, at batch 16 and 64 (a
-per-workgroup fixed cost -- the filter load into registers -- shows as a time that does not scale with the batch).  Run in ONE process per library
-switch: YOLO2_C64=0 / 1 python scripts/c64_bench.py"""
+"""conv2 / conv4 forward (64 -> 128 channels, 104 x 104) and conv1's data gradient (64 -> 32 at 208 x 208): conv_c64.hip against the generic per-tap
+kernel, per epilogue, at batch 16 and 64 (a per-workgroup fixed cost -- the filter load into registers -- shows as a time that does not scale with
+the batch).  Run in ONE process per library switch: YOLO2_C64=0 / 1 python scripts/c64_bench.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -49,3 +49,14 @@ for B in [int(b) for b in os.environ.get("BATCHES", "16,64").split(",")]:
         res.append('%s %.1f us (%.0f TFLOP/s)' % (name, t, 2.0 * M * cout * 9 * cin / t * 1e-6))
         plan = ops.last_conv_plan()
     print('YOLO2_C64=%s batch %d: %s   plan %s' % (os.environ.get('YOLO2_C64', '1'), B, ', '.join(res), '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))
+    # conv1's data gradient: dY 64 channels at 208 x 208 -> dX 32 channels
+    Hn, M = 208, B * 208 * 208
+    dy = torch.randn(M * 64, device='cuda').to(T)
+    dx = torch.zeros(M * 32, dtype=T, device='cuda')
+    wn = torch.randn(9 * 32 * 64, device='cuda') * 0.05
+    Fd = torch.zeros(32 * 9 * 64, dtype=T, device='cuda')
+    ops.filter_prep(wn, None, Fd, 3, 32, 32, 64, 64, T)
+    t = timed(lambda: ops.conv2d_ws(dy, Fd, None, dx, ws, B, Hn, Hn, 64, 64, 32, 32, 3))
+    plan = ops.last_conv_plan()
+    print('YOLO2_C64=%s batch %d: conv1 data gradient %.1f us (%.0f TFLOP/s, %.2f TB/s of 192 B per pixel)   plan %s' % (
+        os.environ.get('YOLO2_C64', '1'), B, t, 2.0 * M * 32 * 9 * 64 / t * 1e-6, M * 192 / t * 1e-6, '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))

@@ -121,6 +121,7 @@ CONV_SHAPES = [
     (3, 40, 33, 32, 64, 3),     # ... more tiles than one workgroup round leaves whole
     (2, 9, 11, 320, 200, 3),    # five chunks; data gradient single-chunk (ldy = 200)
     (2, 12, 20, 64, 128, 3),    # 64 -> 128 channels: the persistent conv2 / conv4 kernel with the filter in registers (conv_c64.hip)
+    (2, 12, 20, 64, 32, 3),     # 64 -> 32: its 32-filter form (conv1's data gradient)
     (1, 7, 9, 64, 128, 3),      # ... one partial tile, odd extents
     (3, 40, 33, 64, 128, 3),    # ... more tiles than one workgroup round leaves whole
 ]
@@ -282,14 +283,17 @@ def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
     assert float(part.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('wgs,shape,c64', [(3, (3, 40, 33, 64, 128, 3), True),     # 16 tiles on 3 workgroups: several tiles each, both halo buffers reused
-                                            (2, (2, 12, 20, 64, 128, 3), True),      # 3 tiles on 2 workgroups
-                                            (0, (2, 26, 27, 64, 128, 3), True),      # the product grid (one workgroup per tile here)
-                                            (0, (1, 4, 320, 64, 128, 3), False)])    # a 320-wide row: two halo buffers do not fit LDS -> the generic kernel
+@pytest.mark.parametrize('wgs,shape,c64', [(3, (3, 40, 33, 64, 128, 3), True),     # 4182 positions on 3 workgroups: six tiles each, the ring wraps
+                                            (1, (3, 40, 33, 64, 128, 3), True),      # ... on one workgroup: 17 tiles, the ring wraps five times
+                                            (2, (2, 12, 20, 64, 128, 3), True),      # 546 positions on 2 workgroups: ranges of 384, the last tile of each partial
+                                            (5, (2, 31, 16, 64, 128, 3), True),      # ranges of 256 positions: one tile per workgroup, the last range short
+                                            (0, (2, 26, 27, 64, 128, 3), True),      # the product grid (one 128-position range per workgroup here)
+                                            (2, (1, 6, 200, 64, 128, 3), True),      # 200-wide rows: 84 first pieces + a filter round = 157 KB of LDS
+                                            (0, (1, 4, 320, 64, 128, 3), False)])    # a 320-wide row: first tile + filter round do not fit LDS -> the generic kernel
 def test_conv_c64_persistent_tiles_and_width_fallback(ops, wgs, shape, c64):
-    """conv_c64.hip (conv2 / conv4 forward: filter in registers, persistent workgroups over 256-position tiles of the padded index).  With the
-    workgroup count forced down every workgroup takes several tiles (double-buffered halo, per-lane statistics carried across tiles).  Output,
-    bias + leaky and the fused batch-norm sums against the oracle; the plan word says which kernel ran."""
+    """conv_c64.hip (conv2 / conv4 forward: filter in registers, persistent workgroups over a contiguous range of the padded index, one ring of
+    pixel rows).  With the workgroup count forced down every workgroup takes several tiles (ring wrap, partial last tiles, per-lane statistics
+    carried across tiles).  Output, bias + leaky and the fused batch-norm sums against the oracle; the plan word says which kernel ran."""
     B, H, W, Cin, Cout, k = shape
     rng = np.random.RandomState(sum(shape) + 13)
     x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
@@ -673,8 +677,42 @@ def test_conv_wgrad_border_only_inputs(ops, shape, mode, which):
         assert_wgrad_exact_products(host(dW).reshape(3, 3, Cin, Cout), ref, 'wgrad border-only %s in %s %s %s' % (which, side, shape, mode))
 
 
+@pytest.mark.parametrize('wgs,shape', [(3, (3, 40, 33)), (1, (2, 31, 16)), (2, (1, 9, 208)), (0, (2, 26, 27))])
+def test_conv_c64_32_filter_form_as_data_gradient(ops, wgs, shape):
+    """conv_c64.hip with 32 filters: the data gradient of a 32 -> 64 channel 3x3 layer (Darknet-19 conv1; reference model/yolo2/inference.py:76) is
+    the forward convolution of dY (64 channels) with the flipped, transposed filters.  Every wave holds the whole operand and takes 32 positions of
+    a tile; accumulators alternate over the K steps.  Against the oracle's conv2d_dgrad; with a bias / activation the call takes the generic kernel."""
+    B, H, W = shape
+    Cin, Cout, k = 32, 64, 3
+    rng = np.random.RandomState(sum(shape) + 77)
+    dy = bf16_round(rng.randn(B, H, W, Cout).astype(np.float32))
+    w = bf16_round((rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cout)).astype(np.float32))
+    T = torch.bfloat16
+    Fd = torch.zeros(Cin * k * k * Cout, dtype=T, device='cuda')
+    ops.filter_prep(dev(w), None, Fd, k, Cin, Cin, Cout, Cout, T)
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    dx = torch.full((B * H * W * Cin,), 5.0, dtype=T, device='cuda')
+    dxl = torch.zeros(B * H * W * Cin, dtype=T, device='cuda')
+    try:
+        if wgs:
+            ops.set_stream_workgroups(wgs)
+        ops.conv2d_ws(dev(dy, T), Fd, None, dx, ws, B, H, W, Cout, Cout, Cin, Cin, k)
+        plan = ops.last_conv_plan()
+        ops.conv2d_bias_leaky(dev(dy, T), Fd, dev(np.zeros(Cin, np.float32)), dxl, ws, B, H, W, Cout, Cout, Cin, Cin, k, 0.1)
+        planl = ops.last_conv_plan()
+        torch.cuda.synchronize()
+    finally:
+        ops.set_stream_workgroups(0)
+    assert (plan['BM'], plan['BN'], plan['stages']) == (256, 32, 9), plan
+    assert (planl['BM'], planl['BN'], planl['stages']) != (256, 32, 9), planl
+    ref = R.conv2d_dgrad(dy.astype(np.float64), w.astype(np.float64))
+    got = host(dx).reshape(B, H, W, Cin).astype(np.float64)
+    assert (np.abs(got - ref) <= 4e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all(), 'c64 32-filter dgrad %s wgs %d: %.3e' % (shape, wgs, np.abs(got - ref).max())
+    assert_close(host(dxl).reshape(B, H, W, Cin), np.maximum(ref, 0.1 * ref), BF16_RTOL, 'generic kernel on the same operands')
+
+
 @pytest.mark.parametrize('which', BORDERS)
-@pytest.mark.parametrize('chan', [(32, 64, 512, 64), (64, 128, 256, 128)], ids=['c32', 'c64'])      # (Cin, Cout, plan BM, plan BN): conv_c32.hip / conv_c64.hip
+@pytest.mark.parametrize('chan', [(32, 64, 512, 64), (64, 128, 256, 128), (64, 32, 256, 32)], ids=['c32', 'c64', 'c64n'])      # (Cin, Cout, plan BM, plan BN): conv_c32.hip / conv_c64.hip (128 and 32 filters)
 @pytest.mark.parametrize('shape', [(2, 12, 20), (1, 7, 9), (3, 40, 33), (2, 31, 16)])
 def test_conv_c32_border_only_inputs(ops, shape, which, chan):
     """conv_c32.hip (conv1 forward, padded position index with one zero column per row and one zero row per image): an input that is non-zero

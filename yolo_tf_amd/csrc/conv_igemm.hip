@@ -1029,6 +1029,20 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
     return 0;
 }
 
+// Does yolo2_conv2d_dgrad_bn take the producer layer's sums from its own epilogue for this shape?  (The answer the launch rule gives before the variant
+// is known: K-sliced variants still fall back inside the call.)  A/B: YOLO2_FUSE_BN_BWD=0 never; YOLO2_FUSE_BN_BWD_NARROW=1 also the 3x3 data gradients
+// with <= 64 filters on >= 100k pixels -- conv4's at batch 16, where the fused epilogue costs the per-tap kernel 32 us and the separate reduction 19:
+// those run plain by default, and a host that asks first (yolo2_conv2d_dgrad_bn_fuses) schedules reduction + folded apply itself.
+static bool y2_dgrad_bn_fuses(int B, int H, int W, int Nf, int ksize, int dtype) {
+    static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;
+    static const bool fuse_narrow = y2_env_int("YOLO2_FUSE_BN_BWD_NARROW", 0) != 0;
+    const int vec = dtype == YOLO2_BF16 ? 8 : 4;
+    return fuse && Nf % vec == 0 && (fuse_narrow || !(ksize == 3 && Nf <= 64 && (long)B * H * W >= 100000));
+}
+extern "C" int yolo2_conv2d_dgrad_bn_fuses(int B, int H, int W, int Nf, int ksize, int dtype) {
+    return (B > 0 && H > 0 && W > 0 && Nf > 0 && (dtype == YOLO2_F32 || dtype == YOLO2_BF16) && y2_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype)) ? 1 : 0;
+}
+
 static int conv2d_impl(const void *P, const void *F, const float *bias, void *O, float *ws, size_t ws_bytes, int B, int H,
                        int W, int Cp, int ldp, int Nf, int ldo, int ksize, int dtype, void *stream, const char *fn,
                        const float *bn_shift = nullptr, float *bn_part = nullptr, float act_alpha = 1.0f, const Y2BnBwd *bwd = nullptr,
@@ -1069,11 +1083,11 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         }
     }
     static const bool c64_direct = y2_env_int("YOLO2_C64", 1) != 0;
-    if (c64_direct && !bwd && y2_c64_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)F & 15) == 0) {      // 64 -> 128 channels (conv2 / conv4): filters in registers (conv_c64.hip)
+    if (c64_direct && !bwd && y2_c64_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)F & 15) == 0) {      // 64 -> 128 channels (conv2 / conv4) and 64 -> 32 (conv1's data gradient): filters in registers (conv_c64.hip)
         const Tune tu = tune_now();
         int rows = 0;
-        if (y2_c64_fwd(P, F, O, B, H, W, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
-            const int plan_[8] = {256, 128, 8, 8, 9, 0, rows, 1};
+        if (y2_c64_fwd(P, F, O, B, H, W, Nf, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
+            const int plan_[8] = {256, Nf, 8, 8, 9, 0, rows, 1};
             for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
             if (bn_part) g_last_stat_rows = rows;
             Y2_CHECK_LAUNCH();
@@ -1082,12 +1096,8 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
     }
     bool stats_done = true;
     if (bwd) {      // data gradient + the producer layer's BN/leaky backward sums (yolo2_conv2d_dgrad_bn)
-        static const bool fuse = y2_env_int("YOLO2_FUSE_BN_BWD", 1) != 0;
         static const bool d1_direct = y2_env_int("YOLO2_D1", 1) != 0;
-        // (A/B: YOLO2_FUSE_BN_BWD_NARROW=1 fuses them again; the default sends the 3x3 data gradients with <= 64 filters on >= 100k pixels -- conv4's at batch 16: its fused epilogue
-        // costs the per-tap kernel 32 us, the separate reduction 19 -- to the two-kernel form)
-        static const bool fuse_narrow = y2_env_int("YOLO2_FUSE_BN_BWD_NARROW", 0) != 0;
-        const bool can = fuse && Nf % vec == 0 && (fuse_narrow || !(ksize == 3 && Nf <= 64 && (long)B * H * W >= 100000));
+        const bool can = y2_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype);
         if (can && d1_direct && bn_part && y2_d1_shape(Cp, ldp, Nf, ldo, ksize, dtype, (long)B * H * W) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)bwd->Y & 15) == 0) {
             // 1x1 data gradient of the wide early stages (conv3 / conv6): persistent kernel with prefetched y vectors and launch-long sums (conv_d1.hip)
             const Tune tu = tune_now();

@@ -72,10 +72,11 @@ bool y2_c32_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
 int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st);
 
-// conv_c64.hip: persistent 3x3 forward for 64-channel inputs and 128 filters (Darknet-19 conv2 / conv4), bf16, filters held in registers.  y2_c64_fwd
-// returns non-zero when the image is too wide for its LDS plan (the caller then takes the generic kernels).
+// conv_c64.hip: persistent 3x3 convolution for 64-channel inputs with 128 filters (Darknet-19 conv2 / conv4 forward) or 32 (conv1's data gradient), bf16,
+// filters held in registers, one ring of pixel rows per workgroup.  y2_c64_fwd returns non-zero when the image is too wide for its LDS plan or the
+// 32-filter form is asked for an epilogue it does not have (the caller then takes the generic kernels).
 bool y2_c64_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);
-int y2_c64_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
+int y2_c64_fwd(const void *P, const void *F, void *O, int B, int H, int W, int Nf, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st);
 
 // conv_d1.hip: persistent 1x1 data gradient + the producer layer's BN / leaky backward sums for the wide early stages (conv3 / conv6), bf16

@@ -322,9 +322,11 @@ class Engine(object):
                 # (measured per layer, profiles/r03_bn_bwd_fusion_per_layer.txt: in a single-stream trace the epilogue sums win 3-10 us per
                 # launch up to 26x26 at batch 16 and lose 1-13 us on the 52x52 / 104x104 layers; with the filter gradients overlapped on the
                 # side stream the whole step is equal either way, so every qualifying layer stays fused)
+                # (round 6: the library's launch rule is asked first -- conv4's data gradient at batch 16 runs plain, its producer's sums come
+                # from the reduction pass that feeds the folded apply pass like every un-fused layer's)
                 if (op['kind'] == 'conv' and x in producers and producers[x]['bn'] and 'fold_bias' not in self.conv[producers[x]['name']]
                         and uses.get(x, 0) == 1 and x not in fused_pool and x in gact and gact[x][1] == x.c and act[producers[x]['y']][1] == x.c
-                        ):
+                        and ops.conv2d_dgrad_bn_fuses(self.B, x.h, x.w, op['cin'], op['ksize'], self.dtype)):
                     bn_bwd_fused[op['name']] = producers[x]
         inp = next(iter(graph.inputs.values()))
         self._bindings[(inp.h, inp.w)] = {'graph': graph, 'act': act, 'gact': gact, 'fused_pool': fused_pool, 'zero_ranges': None, 'tmp_grad': {},

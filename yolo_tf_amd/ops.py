@@ -53,6 +53,15 @@ def conv2d_dgrad_bn(dY, F, dX, ws, B, H, W, Cp, ldp, Nf, ldo, ksize, Yprev, mean
     return bool(pending.value)
 
 
+def conv2d_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype):
+    """Would ``conv2d_dgrad_bn`` take the producer's sums from its epilogue for this data gradient?  (False: the launch rule prefers a plain data
+    gradient there; the caller schedules ``bn_leaky_bwd_reduce_part`` + ``bn_leaky_bwd_apply_fin`` itself.)"""
+    lib = _lib.load()
+    if 'yolo2_conv2d_dgrad_bn_fuses' in _lib.MISSING:       # (an earlier round's library, YOLO2_LIB_BASELINE=1: it always fused)
+        return True
+    return bool(lib.yolo2_conv2d_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype_code(dtype)))
+
+
 def bn_part_to_grads(bn_part, C, dgamma, dbeta):
     call('yolo2_bn_part_to_grads', ptr(bn_part), C, ptr(dgamma), ptr(dbeta), _stream())
 
