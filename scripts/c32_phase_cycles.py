@@ -13,14 +13,23 @@ x = torch.randn(M * cin, device='cuda').to(T); y = torch.zeros(M * cout, dtype=T
 w = torch.randn(9 * cin * cout, device='cuda') * 0.05
 Ff = torch.zeros(cout * 9 * cin, dtype=T, device='cuda')
 ops.filter_prep(w, Ff, None, 3, cin, cin, cout, cout, T)
+part = torch.zeros(2 * 256 * cout, dtype=torch.float32, device='cuda')
+shift = torch.zeros(cout, device='cuda')
+STATS = os.environ.get('STATS', '0') == '1'      # the training forward (MODE 1: + batch-norm partial sums)
 for _ in range(3):
-    ops.conv2d_ws(x, Ff, None, y, ws, B, H, H, cin, cin, cout, cout, 3)
+    if STATS:
+        ops.conv2d_bn(x, Ff, y, ws, B, H, H, cin, cin, cout, cout, 3, shift, part)
+    else:
+        ops.conv2d_ws(x, Ff, None, y, ws, B, H, H, cin, cin, cout, cout, 3)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ['YOLO2_LIB_PATH'])
 buf = (ctypes.c_ulonglong * (256 * 8))()
 print('rc', lib.yolo2_debug_c32_stamps(buf))
 d = torch.tensor(list(buf), dtype=torch.float64).view(256, 8)
-names = ['barrier', 'dma issue', 'mfma loop', 'vmcnt wait', 'epilogue + stores', '-', 'total', 'tiles']
-for sel, lab in ((d[:, 7] == 6, '6-tile WGs'), (d[:, 7] == 5, '5-tile WGs')):
+names = ['barrier', 'dma issue', 'mfma loop', 'vmcnt wait', 'epilogue + stores', 'final sums (per tile)', 'total', 'tiles']
+print('stats' if STATS else 'plain')
+for sel, lab in ((d[:, 7] == 6, '6-tile WGs'), (d[:, 7] == 5, '5-tile WGs'), (d[:, 7] == 4, '4-tile WGs')):
+    if int(sel.sum()) == 0:
+        continue
     m = d[sel].mean(0)
     print(lab, int(sel.sum()), ' | '.join('%s %.0f' % (n, v / (m[7] if i < 6 else 1)) for i, (n, v) in enumerate(zip(names, m))))

@@ -60,3 +60,19 @@ for B in [int(b) for b in os.environ.get("BATCHES", "16,64").split(",")]:
     plan = ops.last_conv_plan()
     print('YOLO2_C64=%s batch %d: conv1 data gradient %.1f us (%.0f TFLOP/s, %.2f TB/s of 192 B per pixel)   plan %s' % (
         os.environ.get('YOLO2_C64', '1'), B, t, 2.0 * M * 32 * 9 * 64 / t * 1e-6, M * 192 / t * 1e-6, '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))
+    # conv1 forward (conv_c32.hip): 32 -> 64 channels at 208 x 208
+    x1 = torch.randn(M * 32, device='cuda').to(T)
+    y1 = torch.zeros(M * 64, dtype=T, device='cuda')
+    w1 = torch.randn(9 * 32 * 64, device='cuda') * 0.05
+    F1 = torch.zeros(64 * 9 * 32, dtype=T, device='cuda')
+    ops.filter_prep(w1, F1, None, 3, 32, 32, 64, 64, T)
+    part1 = torch.zeros(2 * 256 * 64, dtype=torch.float32, device='cuda')
+    shift1, bias1 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    res = []
+    for name, fn in (('plain', lambda: ops.conv2d_ws(x1, F1, None, y1, ws, B, Hn, Hn, 32, 32, 64, 64, 3)),
+                     ('stats', lambda: ops.conv2d_bn(x1, F1, y1, ws, B, Hn, Hn, 32, 32, 64, 64, 3, shift1, part1)),
+                     ('bias+leaky', lambda: ops.conv2d_bias_leaky(x1, F1, bias1, y1, ws, B, Hn, Hn, 32, 32, 64, 64, 3, 0.1))):
+        t = timed(fn)
+        res.append('%s %.1f us (%.2f TB/s of 192 B per pixel)' % (name, t, M * 192 / t * 1e-6))
+        plan = ops.last_conv_plan()
+    print('YOLO2_C64=%s batch %d: conv1 forward %s   plan %s' % (os.environ.get('YOLO2_C64', '1'), B, ', '.join(res), '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))

@@ -234,13 +234,15 @@ def test_conv_bn_fused_statistics(ops, shape, mode):
     np.testing.assert_allclose(host(mv), mv0 - (mv0 - host(var)) * np.float32(1 - 0.999), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize('wgs,shape,c32', [(3, (3, 40, 33, 32, 64, 3), True),      # 9 tiles on 3 workgroups: three tiles each, both halo buffers reused
-                                            (2, (2, 12, 20, 32, 64, 3), True),       # 2 tiles, one per workgroup
-                                            (0, (1, 5, 300, 32, 64, 3), False)])     # a 300-wide row: two halo buffers do not fit LDS -> the generic kernel
+@pytest.mark.parametrize('wgs,shape,c32', [(3, (3, 40, 33, 32, 64, 3), True),      # 4182 positions on 3 workgroups: three tiles each
+                                            (1, (4, 40, 33, 32, 64, 3), True),       # ... 5576 on one workgroup: 11 tiles, the ring wraps five times
+                                            (2, (2, 12, 20, 32, 64, 3), True),       # 2 tiles, one per workgroup, the second range short
+                                            (2, (1, 5, 300, 32, 64, 3), True),       # 300-wide rows: 144 KB of LDS
+                                            (0, (1, 3, 500, 32, 64, 3), False)])     # a 500-wide row: the ring does not fit LDS -> the generic kernel
 def test_conv_c32_persistent_tiles_and_width_fallback(ops, wgs, shape, c32):
-    """conv_c32.hip walks its tiles with one workgroup per CU; with the workgroup count forced down every workgroup takes several tiles
-    (the double-buffered halo, the per-lane statistics carried across tiles).  Output, bias + leaky and the fused batch-norm sums against
-    the oracle; the plan word says which kernel ran."""
+    """conv_c32.hip gives every workgroup one contiguous range of the padded index and keeps one ring of pixel rows over it; with the workgroup
+    count forced down every workgroup takes several tiles (ring wrap, the per-lane statistics carried across tiles).  Output, bias + leaky and the
+    fused batch-norm sums against the oracle; the plan word says which kernel ran."""
     B, H, W, Cin, Cout, k = shape
     rng = np.random.RandomState(sum(shape) + 11)
     x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))

@@ -49,8 +49,32 @@ __device__ __forceinline__ bf16x8 y2_frag16(u32x2 lo, u32x2 hi) {
 __device__ __forceinline__ unsigned y2_lds_addr(const void *p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
 }
+// Sum of v over the lanes that share lane % G (G = 4 .. 64 lanes per group), left in EVERY lane -- on the VALU: row rotations (DPP) inside the
+// 16-lane rows, v_permlane16_swap / v_permlane32_swap across them (with both operands the same value, "swap the odd rows of the first with the even rows
+// of the second" leaves {row 0, row 0, row 2, row 2} and {row 1, row 1, row 3, row 3}: their sum is the pair's total in both rows; likewise the halves).
+// The ds_bpermute butterfly (__shfl_xor) this replaces goes through the LDS pipe: ~7.5 cycles per exchange and CU when eight waves do it at once.
+// (inline asm: with the builtin hipcc 7.2 adds the first result to itself; the s_nop cover the VALU -> permlane hazards the compiler cannot see)
+__device__ __forceinline__ float y2_rows_pair_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float y2_halves_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+template <int G> __device__ __forceinline__ float y2_lane_group_sum(float v) {
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "lanes per group");
+    if (G <= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));      // row_ror:4
+    if (G <= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));      // row_ror:8
+    if (G <= 16) v = y2_rows_pair_sum(v);
+    if (G <= 32) v = y2_halves_sum(v);
+    return v;
+}
 #else
 __device__ inline unsigned y2_lds_addr(const void *) { return 0u; }      // (host pass of a __global__ body)
+template <int G> __device__ inline float y2_lane_group_sum(float v) { return v; }
 #endif
 
 // first-layer direct convolution (conv_first.hip), used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches

@@ -4,26 +4,30 @@
 // generic implicit-GEMM kernel is at its worst: the reduction is only 9 taps x 32 channels = 288 long, so a 128 x 64 tile of the per-tap
 // kernel runs nine K steps of TWO MFMAs per wave between barriers and pays a prologue and an epilogue per 18 MFMAs -- 74 us for 25.5 GFLOP
 // (344 TFLOP/s) although the layer moves only 133 MB.  What this kernel does instead:
-//   * persistent workgroups (one per CU) walk 512-position tiles; the whole filter (64 x 288 bf16, 37 KB) is loaded into LDS ONCE per workgroup;
+//   * persistent workgroups (one per CU) walk 512-position tiles of ONE CONTIGUOUS RANGE of positions each; the whole filter (64 x 288 bf16, 37 KB) is
+//     loaded into LDS ONCE per workgroup;
 //   * the pixels run over a PADDED index q (row pitch W + 1, image pitch H + 1: one zero column per row, one zero row per image -- the
-//     filter-gradient kernel's idea, conv_wgrad3.hip): all nine taps are constant row offsets dh (W + 1) + dw into ONE staged halo image with no
+//     filter-gradient kernel's idea, conv_wgrad3.hip): all nine taps are constant row offsets dh (W + 1) + dw into the staged pixel rows with no
 //     (pixel, tap) mask anywhere; the DMA source offset of a staged row decides whether it is a pixel or a zero;
-//   * a wave computes 64 positions x 64 filters (72 MFMAs per tile on 72 + 72 ds_read_b128), no barrier inside a tile, the next tile's halo
-//     streams into the other buffer meanwhile;
+//   * the staged rows form a RING over the workgroup's range (round 6, from conv_c64.hip): a tile's 2 (W + 2) halo rows are the previous tile's, only
+//     its 512 new rows stream in (by LDS-DMA, under the MFMAs) -- 45 MB per launch instead of the 82 MB two whole halo images per tile re-staged;
+//   * a wave computes 64 positions x 64 filters (72 MFMAs per tile on 72 + 72 ds_read_b128), one raw barrier per tile;
 //   * the MFMA operand roles are swapped (D = F^T X^T: column = lane & 31 = POSITION, rows = filters) and the filter rows are permuted
 //     (c32_slot_filter) so that a lane's 32 accumulator rows are 32 consecutive filters of its position; a 4 x 4 transpose over the lanes of a
 //     quad (DPP) then makes every store instruction write whole 128-byte rows: straight from registers, no LDS staging of the output tile.
-//     The batch-norm partial sums (same contract as conv_igemm.hip's epilogue) run per lane over its position column and meet across lanes
-//     once, after the last tile.
+//     The batch-norm partial sums (same contract as conv_igemm.hip's epilogue) run per lane over its position column and meet once, after the
+//     last tile: across lanes on the VALU (DPP), across the eight waves in LDS, 128 atomics per workgroup into 32 partial rows.
 // W / (W + 1) x H / (H + 1) of the MFMA work is real (99 % at 208 x 208).
 //
-// Measured (batch 16, 208 x 208, MODE 1): 55 us against 70-74 us of the generic kernel.  The kernel is bound by what it moves between L2 and the
-// CUs, not by its 72 MFMAs per wave and tile: 1365 tiles x 60 KB of halo (the 420 halo rows of a 512-position tile re-stage 82 % of it) + 89 MB
-// of output = 171 MB at the ~4.7 TB/s the DMA issue and the stores sustain together (s_memtime stamps per phase: a wave's eight DMA pieces
-// take ~1.7k ticks to ISSUE and its eight stores ~1k, against ~12 ticks per piece from cache: scripts/experiments/lds_dma_issue.hip) -- 36 us if
-// everything overlapped.  Tried on top and measured no better: two wave groups half a tile apart (MFMA loop of one over the epilogue of the
-// other), DMA pieces interleaved into the MFMA steps, half the workgroups delayed by half a tile.  What did pay: whole-row stores (the quad
-// transpose: store issue 1.8k -> 1.0k ticks per tile), packed-f32 branch-free statistics (epilogue 700 -> 380 instructions).
+// Measured (batch 16, 208 x 208; microbenchmark, one call): round 5 (two halo images, ds_bpermute butterfly, 1024 atomics per workgroup into 228 rows)
+// plain store 35.0 us, + statistics 55.2 us; round 6 31.6-32.7 / 39.6 us; the generic kernel 70-74 us.  s_memtime stamps (scripts/c32_phase_cycles.py,
+// STATS=1) showed where the 20 us between "plain" and "+ statistics" were: 12 us in the final butterfly (64 values x 5 ds_bpermute per wave: all
+// through the LDS pipe) and most of the rest in same-address atomics; the per-tile arithmetic of the sums costs ~0.9 us per tile.  The kernel is
+// bound by what it moves between L2 and the CUs, not by its 72 MFMAs per wave and tile: 133 MB at the ~4.2 TB/s DMA issue and stores sustain together
+// (a wave's DMA pieces take ~0.8k cycles to ISSUE per tile and its eight stores ~1k, against ~12 ticks per piece from cache:
+// scripts/experiments/lds_dma_issue.hip).  Tried in round 5 and measured no better: two wave groups half a tile apart (MFMA loop of one over the
+// epilogue of the other), DMA pieces interleaved into the MFMA steps, half the workgroups delayed by half a tile.  What did pay: whole-row stores (the
+// quad transpose: store issue 1.8k -> 1.0k ticks per tile), packed-f32 branch-free statistics (epilogue 700 -> 380 instructions).
 #include "common.h"
 #include "conv_shared.h"
 #include <atomic>
@@ -31,6 +35,7 @@
 #define C32_TP 512                 // padded positions per tile (8 waves x 64)
 #define C32_FROWB 592              // LDS bytes per filter row: 576 + 16 (row stride 148 banks: the 16 lanes of a read group hit 16 different bank quads)
 #define C32_FBYTES (64 * C32_FROWB)
+#define C32_STAT_ROWS 32           // partial rows the statistics are spread over (the consumer's prologue sums every row in use)
 
 // MFMA output row rho of filter block j lands in register r = (rho & 3) + 4 (rho >> 3) of the lanes of half h = (rho >> 2) & 1.  Giving that row
 // filter 32 h + 16 j + r makes the 32 values of a lane (2 blocks x 16 registers) 32 CONSECUTIVE filters: 64 contiguous bytes of its position's row.
@@ -51,19 +56,33 @@ __device__ unsigned long long c32_stamps[256 * 8];
 #define C32_ABL(bit) 0
 #endif
 
+struct C32Geo {
+    int H, W, M, Mp;       // image rows / columns, pixels, padded positions of the batch
+    int L;                 // padded positions per workgroup (a multiple of the 512-position tile)
+    int RR;                // ring rows of 64 bytes (a multiple of 64)
+    int HLa;               // ring row of the workgroup's first position: W + 2 rounded up to 16
+    int NP0;               // 16-row pieces staged before the first tile
+    unsigned mP, sP, mH, sH;
+};
+
 template <int MODE>
 __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
-    const bf16 *__restrict__ X, unsigned x_bytes, const bf16 *__restrict__ F, unsigned f_bytes, bf16 *__restrict__ O, int H, int W, int M, int Mp,
-    int ntiles, int HR, const float *__restrict__ vec, float *__restrict__ bn_part, float alpha, unsigned mP, unsigned sP, unsigned mH, unsigned sH, int abl) {
+    const bf16 *__restrict__ X, unsigned x_bytes, const bf16 *__restrict__ F, unsigned f_bytes, bf16 *__restrict__ O, C32Geo g,
+    const float *__restrict__ vec, float *__restrict__ bn_part, float alpha, int abl) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char *const fl = smem;                        // filter image [64][C32_FROWB]
-    unsigned char *const hb = smem + C32_FBYTES;           // two halo buffers of HR rows x 64 bytes
-    const int HB = HR * 64;
+    unsigned char *const hb = smem + C32_FBYTES;           // the ring: RR rows x 64 bytes
+    const int H = g.H, W = g.W, Mp = g.Mp;
+    const unsigned mP = g.mP, sP = g.sP, mH = g.mH, sH = g.sH;
+    const int RRB = g.RR * 64, NPR = g.RR >> 4;             // ring bytes, ring pieces
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const unsigned P1 = (unsigned)(W + 1), H1 = (unsigned)(H + 1);
-    const int HL = W + 2;                                  // halo rows in front of a tile: the farthest tap is (W + 1) + 1 positions back
+    const int s0 = (int)blockIdx.x * g.L;                   // this workgroup's positions [s0, e0): ONE contiguous range, so that a tile's halo rows
+    const int e0 = min(s0 + g.L, Mp);                       // are the previous tile's and only its 512 new rows are staged (conv_c64.hip's ring)
+    if (s0 >= Mp) return;
+    const int pbase = s0 - g.HLa;                          // padded position of ring row 0 (may be negative: those rows stage as zeros)
 
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(X), 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(F), 0, f_bytes, 0x00020000);
@@ -77,41 +96,38 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (lds_void_ptr)(fl + p * 1024), 16, voff, 0, 0, 0);
     }
 
-    // ---- halo staging: piece p of a buffer = rows 16 p .. 16 p + 15 (64 bytes each); lane = (row = lane >> 2, 16-byte chunk = lane & 3), source chunk
-    // swizzled with (row >> 2) & 3 so that the 16 rows a ds_read_b128 lane group touches -- whatever row a tap offset starts them at -- land on 16
-    // different bank quads.  A staged row is padded position q0 - HL + row: a pixel, or zeros (zero column, zero row, outside the batch).
-    const int npieces = HR >> 4;
+    // ---- ring staging: piece j = ring rows 16 j .. 16 j + 15 (64 bytes each) = padded positions pbase + 16 j ..; lane = (row = lane >> 2, 16-byte chunk =
+    // lane & 3), source chunk swizzled with (row >> 2) & 3 so that the 16 rows a ds_read_b128 lane group touches -- whatever row a tap offset starts
+    // them at -- land on 16 different bank quads (RR is a multiple of 16: the term survives the wrap).  A staged row is a pixel, or zeros (zero column,
+    // zero row, outside the batch).
     const int prow = lane >> 2;
     const unsigned pchunk = (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
     // one piece: q -> (R = q / (W + 1), img = R / (H + 1)); the pixel index is m = q - R - img W (q = R (W + 1) + c, R = img (H + 1) + r, m = (img H + r) W + c)
-    auto stage_piece = [&](int q0, int buf, int p) {
-        const unsigned q = (unsigned)(q0 + p * 16 + prow);                     // wraps below 0: fails the range test
+    auto stage_piece = [&](int j, int slot) {
+        const unsigned q = (unsigned)(pbase + j * 16 + prow);                  // wraps below 0: fails the range test
         const unsigned R = c32_div(q, mP, sP);                                 // padded image row over the whole batch
         const unsigned img = c32_div(R, mH, sH);
         const unsigned c = q - __umul24(R, P1), r = R - __umul24(img, H1);
         const bool ok = (q < (unsigned)Mp) & (c < (unsigned)W) & (r < (unsigned)H);
         const unsigned m = q - R - __umul24(img, (unsigned)W);
         const unsigned voff = ok ? m * 64u + pchunk : Y2_OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_ptr)(hb + buf * HB + p * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_ptr)(hb + slot * 1024), 16, voff, 0, 0, 0);
     };
-    auto stage = [&](int tile, int buf, int p0, int pstep) {
-        const int q0 = tile * C32_TP - HL;
-        for (int p = p0; p < npieces; p += pstep) stage_piece(q0, buf, p);
-    };
-    int tile = blockIdx.x;
-    if (tile < ntiles) stage(tile, 0, wave, 8);
+    for (int j = wave; j < g.NP0; j += 8) stage_piece(j, j);                  // rows [0, HLa + TP + W + 2): the first tile and both its halos
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the filter and this wave's pieces of the first tile have landed
 
-    // ---- read addresses (buffer 0; the other buffer is + HB).  A (pixels, the MFMA's B operand): one per (tap, position block); the two 16-channel
-    // groups of a tap differ by XOR 32 (bit 1 of the chunk index).  B (filters, the MFMA's A operand): row l31 (+ 32 j), 8 k-values of this lane's half.
+    // ---- read addresses (ring offset 0), relative to the ring.  A (pixels, the MFMA's B operand): one per tap for position block 0; a tile / block moves
+    // it by a multiple of 32 rows (same swizzle: (row >> 2) & 3), wrapped at the ring's end; the two 16-channel groups of a tap differ by XOR 32 (bit 1
+    // of the chunk index).  B (filters, the MFMA's A operand): row l31 (+ 32 j), 8 k-values of this lane's half.
     const unsigned lds0 = y2_lds_addr(smem);
-    unsigned aaddr[9];                                     // position block 0; block 1 is 32 rows = + 2048 bytes on (same swizzle: (row >> 2) & 3)
+    unsigned abase[9];
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
         const int shift = (tp / 3 - 1) * (W + 1) + (tp % 3 - 1);
-        const int row = wave * 64 + l31 + HL + shift;
-        aaddr[tp] = lds0 + (unsigned)(C32_FBYTES + row * 64 + (((half) ^ ((row >> 2) & 3)) << 4));
+        const int row = wave * 64 + l31 + g.HLa + shift;
+        abase[tp] = (unsigned)(row * 64 + (((half) ^ ((row >> 2) & 3)) << 4));
     }
+    const unsigned ring0 = lds0 + (unsigned)C32_FBYTES;
     const unsigned baddr = lds0 + (unsigned)(l31 * C32_FROWB + half * 16);       // filter block 0; block 1 is 32 rows on
 
     // per-filter constants of this lane's 2 x 16 accumulator rows: filter f(j, r) = 32 half + 16 j + r (c32_slot_filter).  MODE 2 keeps the bias in
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
     typedef __attribute__((ext_vector_type(2))) float f32x2;
     float cst[2][16];
     f32x2 t1[2][8], t2[2][8];                               // packed pairs: the sums run on v_pk_add_f32 / v_pk_fma_f32
-    float *const shl = reinterpret_cast<float *>(hb + 2 * HB);
+    float *const shl = reinterpret_cast<float *>(hb + RRB);
     if (MODE == 1 && tid < 64) shl[tid] = vec ? vec[tid] : 0.f;
     if (MODE == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the loop's barriers are raw: this write is on its way before the first one)
 #pragma unroll
@@ -134,18 +150,29 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
         }
 
     typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
-    const int T = tile < ntiles ? (ntiles - tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;      // tiles of this workgroup
+    const int T = (e0 - s0 + C32_TP - 1) / C32_TP;          // tiles of this workgroup
+    int pslot = g.NP0;                                      // ring piece the next tile's first new piece goes to (NP0 + 32 t, wrapped)
+    if (pslot >= NPR) pslot -= NPR;
+    unsigned tro = 0;                                       // ring byte offset of the current tile (512 t rows, wrapped)
+    int tb = s0;                                            // first position of the current tile
     f32x16 acc[2][2];                                                // [filter block j][position block i]
 #ifdef Y2C32_EXPERIMENTS
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
     const unsigned long long t00 = tl;
 #endif
     auto mfma_phase = [&](int t) {
-        tile = (int)blockIdx.x + t * (int)gridDim.x;
-        const int buf = t & 1;
-        if (t + 1 < T && !C32_ABL(4)) stage(tile + (int)gridDim.x, buf ^ 1, wave, 8);       // this wave's pieces of the next tile, into the buffer every wave left before the barrier
+        if (t + 1 < T && !C32_ABL(4)) {                      // this wave's pieces of the next tile's 512 new rows, over rows every wave left before the barrier
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = wave + 8 * u;
+                int sl = pslot + k;
+                if (sl >= NPR) sl -= NPR;
+                stage_piece(g.NP0 + t * 32 + k, sl);
+            }
+        }
+        pslot += 32;
+        if (pslot >= NPR) pslot -= NPR;
         C32_STAMP(1);
-        const unsigned boff = buf ? (unsigned)HB : 0u;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -155,11 +182,20 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
         // 18 steps (tap, 16-channel group) of 4 fragment reads + 4 MFMAs; the reads of step s + 1 are issued ahead of the MFMAs of step s (two
         // fragment sets: left to itself hipcc keeps one and waits lgkmcnt(0) in front of nearly every MFMA)
         bf16x8 fa[2][2], fb[2][2];
+        unsigned ad[2];
         auto load = [&](int st, int set) {
             const int tp = st >> 1, kk = st & 1;
-            const unsigned pa = (aaddr[tp] ^ (unsigned)(kk * 32)) + boff;
+            if (kk == 0) {                                  // a tap's addresses are formed when its first group is read
+                unsigned x = abase[tp] + tro;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) fa[set][i] = *(lds_frag_ptr)(uintptr_t)(pa + (unsigned)(i * 2048));
+                for (int i = 0; i < 2; ++i) {
+                    x = min(x, x - (unsigned)RRB);          // wrap (x < ring: the difference wraps to a huge value)
+                    ad[i] = x + ring0;
+                    x += 2048u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[set][i] = *(lds_frag_ptr)(uintptr_t)(ad[i] ^ (unsigned)(kk * 32));
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[set][j] = *(lds_frag_ptr)(uintptr_t)(baddr + (unsigned)(j * 32 * C32_FROWB + tp * 64 + kk * 32));
         };
@@ -179,7 +215,6 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
         C32_STAMP(2);
     };
     auto epilogue_phase = [&](int t) {
-        tile = (int)blockIdx.x + t * (int)gridDim.x;
         // ---- epilogue: D[filter][position].  Round (MODE 2: bias + leaky first), statistics of the rounded values, pack pairs, swap halves:
         // a lane holds filters 32 half + [0, 32) of its position.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -191,12 +226,12 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
         const unsigned lo = (unsigned)(64 * half + 16 * (lane & 3));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const unsigned q = (unsigned)(tile * C32_TP + wave * 64 + i * 32 + l31);
+            const unsigned q = (unsigned)(tb + wave * 64 + i * 32 + l31);
             const unsigned R = c32_div(q, mP, sP);
             const unsigned c = q - __umul24(R, P1);
             const unsigned img = c32_div(R, mH, sH);
             const unsigned r_ = R - __umul24(img, H1);
-            const bool live = (q < (unsigned)Mp) & (c < (unsigned)W) & (r_ < (unsigned)H);
+            const bool live = (q < (unsigned)e0) & (c < (unsigned)W) & (r_ < (unsigned)H);
             const unsigned m = __umul24(__umul24(img, (unsigned)H) + r_, (unsigned)W) + c;
             const unsigned moff = live ? m * 128u : 0xffffffffu;           // byte offset of this lane's position row (Mp < 2^24)
             const float lf = live ? 1.0f : 0.0f;
@@ -275,41 +310,59 @@ __global__ __launch_bounds__(512) void conv_c32_fwd_kernel(
 #endif
     };
     // One RAW barrier per tile (__syncthreads() would also wait for the output stores in flight, vmcnt(0)): every wave's pieces of tile t have landed
-    // (each waited for its own in its previous epilogue) and every wave has left the other buffer.
+    // (each waited for its own in its previous epilogue) and every wave has left the rows the new pieces overwrite.
     for (int t = 0; t < T; ++t) {
         __builtin_amdgcn_s_barrier();
         C32_STAMP(0);
         mfma_phase(t);
         epilogue_phase(t);
+        tb += C32_TP;
+        tro += (unsigned)(C32_TP * 64);
+        if (tro >= (unsigned)RRB) tro -= (unsigned)RRB;
     }
     if (MODE == 1 && bn_part) {
-        // a lane holds the sums of its 32 filters over its position column: they meet across the 32 lanes of each half.  Step-major -- all 64
-        // exchanges of a step in flight together, then the adds: value-major (64 chains of 5 dependent ds_bpermute round trips, a wait behind each)
-        // cost 21 us per workgroup, a third of the kernel
+        // a lane holds the sums of its 32 filters over its position column: they meet across the 32 lanes of each half on the VALU (DPP: quad, quad pair,
+        // row, then lane 15 of rows 0 / 2 into rows 1 / 3 -- six instructions per value).  The ds_bpermute butterfly this replaces -- 64 values x 5 steps
+        // per wave, all through the LDS pipe -- took 12 us per workgroup (s_memtime stamps), a quarter of the launch.
         float v1[32], v2[32];
+        auto halfsum = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));        // quad_perm [1,0,3,2]
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));        // quad_perm [2,3,0,1]
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));       // row_half_mirror: the other quad of 8
+            v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));       // row_mirror: the other 8 of 16
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false)); // row_bcast:15 into rows 1 and 3
+            return v;                                                                                                           // lanes 16-31 / 48-63: the half's total
+        };
 #pragma unroll
-        for (int k = 0; k < 32; ++k) { v1[k] = t1[k >> 4][(k & 15) >> 1][k & 1]; v2[k] = t2[k >> 4][(k & 15) >> 1][k & 1]; }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-            float x1[32], x2[32];
-#pragma unroll
-            for (int k = 0; k < 32; ++k) { x1[k] = __shfl_xor(v1[k], o, 64); x2[k] = __shfl_xor(v2[k], o, 64); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < 32; ++k) { v1[k] += x1[k]; v2[k] += x2[k]; }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (l31 == 0) {
-            const int slot = (int)(blockIdx.x & (Y2_BN_PART_ROWS - 1));
+        for (int k = 0; k < 32; ++k) { v1[k] = halfsum(t1[k >> 4][(k & 15) >> 1][k & 1]); v2[k] = halfsum(t2[k >> 4][(k & 15) >> 1][k & 1]); }
+        // ... and across the eight waves in LDS (the ring is idle now) before anything leaves the CU: 128 atomics per workgroup instead of 1024 onto the
+        // same 128 addresses (same-address f32 atomics serialise at L2, ~0.1 us each and more under contention: measured 20 us of this launch)
+        __builtin_amdgcn_s_barrier();                              // every wave is past its last MFMA loop (raw: __syncthreads() would also wait for the output stores in flight)
+        float *const red = reinterpret_cast<float *>(hb);           // [wave][plane][filter]
+        if (l31 == 16) {
 #pragma unroll
             for (int k = 0; k < 32; ++k) {
-                const int j = k >> 4, r = k & 15;
-                const int f = 32 * half + 16 * j + r;
-                unsafeAtomicAdd(bn_part + slot * 64 + f, v1[k]);
-                unsafeAtomicAdd(bn_part + (Y2_BN_PART_ROWS + slot) * 64 + f, v2[k]);
+                red[(wave * 2 + 0) * 64 + 32 * half + k] = v1[k];   // filter 32 half + 16 j + r with k = 16 j + r
+                red[(wave * 2 + 1) * 64 + 32 * half + k] = v2[k];
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid < 128) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += red[w * 128 + tid];
+            const int slot = (int)(blockIdx.x & (C32_STAT_ROWS - 1));
+            unsafeAtomicAdd(bn_part + ((tid >> 6) * Y2_BN_PART_ROWS + slot) * 64 + (tid & 63), a);
+        }
     }
+    C32_STAMP(5);
+#ifdef Y2C32_EXPERIMENTS
+    if ((abl & 8) && tid == 0) {
+        ph[6] = __builtin_readcyclecounter() - t00;
+        for (int k = 0; k < 8; ++k) c32_stamps[blockIdx.x * 8 + k] = ph[k];
+    }
+#endif
 }
 
 #ifdef Y2C32_EXPERIMENTS
@@ -322,19 +375,24 @@ bool y2_c32_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype) { retu
 int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st) {
     const long Mp = (long)B * (H + 1) * (W + 1);
-    const int HR = (C32_TP + 2 * (W + 2) + 15) / 16 * 16;
-    const size_t lds = (size_t)C32_FBYTES + 2 * (size_t)HR * 64 + 256;      // filter image, two halo buffers, 64 shifts
-    if (lds > 160 * 1024 || Mp + C32_TP >= (1L << 24) || H < 1 || W < 1) return 1;
-    const int M = B * H * W, ntiles = (int)((Mp + C32_TP - 1) / C32_TP);
-    const int grid = ntiles < cus ? ntiles : cus;
+    if (Mp + 2 * C32_TP >= (1L << 24) || H < 1 || W < 1 || cus < 1) return 1;
+    C32Geo g;
+    g.H = H; g.W = W; g.M = B * H * W; g.Mp = (int)Mp;
+    g.L = (int)(((Mp + cus - 1) / cus + C32_TP - 1) / C32_TP) * C32_TP;
+    const int grid = (int)((Mp + g.L - 1) / g.L);
+    g.HLa = (W + 2 + 15) & ~15;
+    g.NP0 = (g.HLa + C32_TP + W + 2 + 15) / 16;
+    g.RR = (16 * g.NP0 + C32_TP + 63) & ~63;                 // the rows of tile t (from its front halo on) and the new rows of tile t + 1
+    const size_t lds = (size_t)C32_FBYTES + (size_t)g.RR * 64 + 256;      // filter image, the ring, 64 shifts
+    if (lds > 160 * 1024) return 1;
+    const int M = g.M;
 #ifdef Y2C32_EXPERIMENTS
     static const int abl = y2_env_int("YOLO2_C32_ABL", 0);      // timing ablations (wrong results): 1 no MFMA loop, 2 no stores, 4 no DMA after the first tile, 8 phase stamps
 #else
     const int abl = 0;
 #endif
-    unsigned mP, sP, mH, sH;
-    y2_magic_u32((unsigned)(W + 1), &mP, &sP);
-    y2_magic_u32((unsigned)(H + 1), &mH, &sH);
+    y2_magic_u32((unsigned)(W + 1), &g.mP, &g.sP);
+    y2_magic_u32((unsigned)(H + 1), &g.mH, &g.sH);
     const unsigned x_bytes = (unsigned)((size_t)M * 32 * 2), f_bytes = 64u * 288u * 2u;
     static std::atomic<size_t> lds_set[3][64];
     int dev = 0;
@@ -345,13 +403,12 @@ int y2_c32_fwd(const void *P, const void *F, void *O, int B, int H, int W, const
             if (hipFuncSetAttribute((const void *)conv_c32_fwd_kernel<MODEv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1; \
             lds_set[MODEv][dev].store(lds, std::memory_order_relaxed);                                                                       \
         }                                                                                                                                    \
-        conv_c32_fwd_kernel<MODEv><<<grid, 512, lds, st>>>((const bf16 *)P, x_bytes, (const bf16 *)F, f_bytes, (bf16 *)O, H, W, M, (int)Mp, ntiles, HR, \
-                                                          vecp, bn_part, alpha, mP, sP, mH, sH, abl);                                             \
+        conv_c32_fwd_kernel<MODEv><<<grid, 512, lds, st>>>((const bf16 *)P, x_bytes, (const bf16 *)F, f_bytes, (bf16 *)O, g, vecp, bn_part, alpha, abl); \
     } while (0)
     if (bn_part) C32_LAUNCH(1, bn_shift);
     else if (bias || alpha != 1.0f) C32_LAUNCH(2, bias);      // (an activation without a bias: the constants read as zeros)
     else C32_LAUNCH(0, (const float *)nullptr);
 #undef C32_LAUNCH
-    if (rows) *rows = grid < Y2_BN_PART_ROWS ? grid : Y2_BN_PART_ROWS;
+    if (rows) *rows = grid < C32_STAT_ROWS ? grid : C32_STAT_ROWS;
     return 0;
 }

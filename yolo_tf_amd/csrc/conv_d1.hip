@@ -157,12 +157,10 @@ __global__ __launch_bounds__(512) void conv_d1_dgrad_bn_kernel(
     }
     // ---- the lanes that share a channel chunk meet (lane % 8 fixed: offsets 8, 16, 32), then one atomic add per value
 #pragma unroll
-    for (int off = WCPR; off < 64; off <<= 1)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            ps[0][k] += __shfl_xor(ps[0][k], off, 64);
-            ps[1][k] += __shfl_xor(ps[1][k], off, 64);
-        }
+    for (int k = 0; k < VEC; ++k) {
+        ps[0][k] = y2_lane_group_sum<WCPR>(ps[0][k]);
+        ps[1][k] = y2_lane_group_sum<WCPR>(ps[1][k]);
+    }
     // ... and the four wave rows of the workgroup (the same channels per column half) in LDS: a quarter of the atomic adds
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                                       // every wave is done with the operand buffers

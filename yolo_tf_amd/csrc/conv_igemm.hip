@@ -531,13 +531,12 @@ __global__ __launch_bounds__(NW * 64) void conv_igemm_kernel(
             }
         }
         if (bstats) {
+            // (the lanes that share a channel chunk meet on the VALU: common.h y2_lane_group_sum)
 #pragma unroll
-            for (int off = WCPR; off < 64; off <<= 1)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    ps[0][k] += __shfl_xor(ps[0][k], off, 64);
-                    ps[1][k] += __shfl_xor(ps[1][k], off, 64);
-                }
+            for (int k = 0; k < VEC; ++k) {
+                ps[0][k] = y2_lane_group_sum<WCPR>(ps[0][k]);
+                ps[1][k] = y2_lane_group_sum<WCPR>(ps[1][k]);
+            }
             // The WGM wave rows of the tile hold sums of the SAME channels.  Where the LDS plan leaves room behind the tile image they meet there and the
             // tile leaves ONE partial row per filter (the host counts rows per pixel tile then: y2_bnbwd_rows_per_tile) -- a WGM-th of the adds and of
             // the (tile, wave row) pairs competing for the partial rows: same-address f32 atomics serialise at ~0.1 us each

@@ -665,13 +665,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
             }
         }
         if (bstats) {
+            // (the lanes that share a channel chunk meet on the VALU: common.h y2_lane_group_sum)
 #pragma unroll
-            for (int off = WCPR; off < 64; off <<= 1)
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    ps[0][k] += __shfl_xor(ps[0][k], off, 64);
-                    ps[1][k] += __shfl_xor(ps[1][k], off, 64);
-                }
+            for (int k = 0; k < VEC; ++k) {
+                ps[0][k] = y2_lane_group_sum<WCPR>(ps[0][k]);
+                ps[1][k] = y2_lane_group_sum<WCPR>(ps[1][k]);
+            }
             // The four wave rows of the tile hold sums of the SAME channels: they meet in LDS (the 7 KiB between the tile image and the idle-DMA sink) and
             // the tile leaves ONE partial row per filter -- a quarter of the adds, and at most 169 pixel tiles instead of 676 (tile, wave row) pairs
             // competing for the partial rows: same-address f32 atomics were 12 us of the 52 x 52 launch's 52 (profiles/r06_pp_bn_epilogue.txt)
