@@ -220,6 +220,14 @@ int yolo2_bn_leaky_pool_bwd_apply_fin(const void *dP, int lddp, const unsigned c
                                       const float *var, const float *gamma, const float *beta, const float *part, int rows,
                                       long plane_stride, float *dgamma, float *dbeta, void *dY, int B, int H, int W, int C, float eps,
                                       float alpha, float *zero, long zero_floats, int dtype, void *stream);
+/* The image layer (3 channels in an 8-wide pixel, 32 filters, 3x3 + batch_norm + leaky_relu + 2x2 max_pool: reference model/yolo2/inference.py:62-66):
+ * yolo2_bn_leaky_pool_bwd_apply_fin + yolo2_conv2d_wgrad in ONE launch.  The layer's output gradient (the largest tensor of the network) is formed
+ * per 32-pixel row segment in LDS from the raw forward output Y [B,H,W,32], the pooled gradient dP [B,H/2,W/2,lddp] and the arg-max codes idx
+ * [B,H/2,W/2,32] and consumed there by the filter-gradient MFMAs; dgamma / dbeta come from the partial rows like in the *_fin call.  dW [3][3][Cin][32]
+ * f32 is ACCUMULATED into (zero it first); X [B,H,W,8]. */
+int yolo2_first_layer_wgrad_bn(const void *X, const void *Y, const void *dP, int lddp, const unsigned char *idx, const float *mean, const float *var,
+                               const float *gamma, const float *beta, const float *part, int rows, long plane_stride, float *dgamma, float *dbeta,
+                               float *dW, int B, int H, int W, int Cin, float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream);
 /* pass 1 of the BN + leaky backward alone: partial rows [2][*rows][C] (f32) left in ws for a *_bwd_apply_fin call */
 int yolo2_bn_leaky_bwd_reduce_part(const void *dA, int ldda, const void *Y, const float *mean, const float *var, const float *gamma,
                                    const float *beta, double *ws, int *rows, int rows_limit, long M, int C, float eps, float alpha,

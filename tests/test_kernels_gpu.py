@@ -966,6 +966,74 @@ def test_bn_leaky_forward_backward(ops, shape, mode):
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 64, 96), (1, 32, 32), (3, 18, 40), (2, 12, 72), (2, 416, 416)])
+def test_first_layer_wgrad_with_bn_backward_inside(ops, shape, mode):
+    """yolo2_first_layer_wgrad_bn (conv_first_wgrad_bn_kernel: the image layer's output gradient formed in LDS from the raw forward output, the pooled
+    gradient and the arg-max codes, and consumed there by the filter-gradient MFMAs) against the two launches it replaces --
+    yolo2_bn_leaky_pool_bwd_apply_fin + yolo2_conv2d_wgrad, both pinned to the oracle by the tests above -- and, on the small shapes, the oracle's own
+    bn_train_bwd / max_pool_grad / conv2d_wgrad chain.  Widths that are not a multiple of the 32-pixel segment (40, 72) exercise the dead pixels of a
+    segment, which must contribute exactly nothing."""
+    B, H, W = shape
+    tdtype = torch.float32 if mode == 'f32' else torch.bfloat16
+    q = (lambda a: a) if mode == 'f32' else bf16_round
+    rng = np.random.RandomState(H * 7 + W)
+    img = q(rng.randn(B, H, W, 3).astype(np.float32))
+    x = dev(pad_channels(img, 8), tdtype)
+    M, MP = B * H * W, B * (H // 2) * (W // 2)
+    y_np = q((rng.randn(B, H, W, 32) * 1.5 + 0.3).astype(np.float32))
+    y = dev(y_np, tdtype)
+    mean, var = dev((rng.randn(32) * 0.3).astype(np.float32)), dev((rng.rand(32) + 0.5).astype(np.float32))
+    gamma, beta = dev((rng.rand(32) + 0.5).astype(np.float32)), dev((rng.randn(32) * 0.2).astype(np.float32))
+    # pooled activation + arg-max codes from the product's own forward (so that the codes are the ones a step would hold)
+    P0 = torch.zeros(MP * 32, dtype=tdtype, device='cuda')
+    idx = torch.full((MP * 32,), 9, dtype=torch.uint8, device='cuda')
+    ops.bn_leaky_pool(y, mean, var, gamma, beta, P0, idx, B, H, W, 32, 32, 1e-5, 0.1)
+    dp_np = q(rng.randn(B, H // 2, W // 2, 32).astype(np.float32))
+    dpd = dev(dp_np, tdtype)
+    ws = torch.zeros(ops.workspace_bytes('bn', 32) // 4 + 2 * 1024 * 32, dtype=torch.float32, device='cuda')
+    limit = ops.bn_fin_rows_limit(32, tdtype)
+    assert limit >= 128
+    rows = ops.bn_leaky_pool_bwd_reduce_part(dpd, 32, idx, y, mean, var, gamma, beta, ws, limit, B, H, W, 32, 1e-5, 0.1)
+    # ---- the two launches
+    dg0, db0 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    dy0 = torch.zeros(M * 32, dtype=tdtype, device='cuda')
+    ops.bn_leaky_pool_bwd_apply_fin(dpd, 32, idx, y, mean, var, gamma, beta, ws, rows, rows * 32, dg0, db0, dy0, B, H, W, 32, 1e-5, 0.1)
+    dW0 = torch.zeros(9 * 3 * 32, dtype=torch.float32, device='cuda')
+    ops.conv2d_wgrad(x, dy0, dW0, B, H, W, 3, 8, 32, 32, 3)
+    # ---- one launch (+ a buffer to clear on the side, like the engine hands it)
+    dg1, db1 = torch.zeros(32, device='cuda'), torch.zeros(32, device='cuda')
+    dW1 = torch.zeros(9 * 3 * 32, dtype=torch.float32, device='cuda')
+    junk = torch.full((4096,), 3.0, dtype=torch.float32, device='cuda')
+    ops.first_layer_wgrad_bn(x, y, dpd, 32, idx, mean, var, gamma, beta, ws, rows, rows * 32, dg1, db1, dW1, B, H, W, 3, 1e-5, 0.1, junk, 4096)
+    torch.cuda.synchronize()
+    assert float(junk.abs().max()) == 0.0
+    assert_close(host(dg1), host(dg0), 1e-6, 'dgamma')
+    assert_close(host(db1), host(db0), 1e-6, 'dbeta')
+    ref = host(dW0).reshape(3, 3, 3, 32)
+    got = host(dW1).reshape(3, 3, 3, 32)
+    # same operands up to the last bit of a few dY elements (the two compilations may contract the f32 multiply-adds differently), f32 sums in another order
+    tol = 2e-5 if mode == 'f32' else 2e-3
+    assert np.abs(got - ref).max() <= tol * np.abs(ref).max(), 'dW fused vs two launches %s %s: %.3e of %.3e' % (shape, mode, np.abs(got - ref).max(), np.abs(ref).max())
+    if M <= 20000:        # the oracle directly
+        dgo, dbo = host(dg0).astype(np.float64), host(db0).astype(np.float64)
+        mu, inv = host(mean).astype(np.float64), 1.0 / np.sqrt(host(var).astype(np.float64) + 1e-5)
+        ga, bt = host(gamma).astype(np.float64), host(beta).astype(np.float64)
+        y64 = y_np.astype(np.float64)
+        xh = (y64 - mu) * inv
+        z = xh * ga + bt
+        # routed by the arg-max codes the forward stored (k = 2 * row parity + column parity; pinned to the oracle's first-maximum rule by the pool
+        # tests above -- recomputing the arg-max here in f64 would differ from the bf16 forward wherever two rounded activations tie)
+        codes = host(idx).reshape(B, H // 2, W // 2, 32)
+        da = np.zeros((B, H, W, 32))
+        for k in range(4):
+            da[:, (k >> 1)::2, (k & 1)::2, :] = np.where(codes == k, dp_np.astype(np.float64), 0.0)
+        g = np.where(z >= 0, da, 0.1 * da)
+        dy = q(((ga * inv) * (g - dbo / M - xh * (dgo / M))).astype(np.float32))
+        dWo = R.conv2d_wgrad(img.astype(np.float64), dy.astype(np.float64), 3, 3)
+        assert np.abs(got - dWo).max() <= (2e-4 if mode == 'f32' else 4e-3) * np.abs(dWo).max(), 'dW fused vs oracle %s %s' % (shape, mode)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 64, 96), (1, 32, 32), (3, 18, 40), (2, 416, 416)])
 def test_first_layer_fused_with_bn_leaky_pool(ops, shape, mode):
     """yolo2_first_layer_* (the image layer's output recomputed inside its consumers, never stored) against the stored-output path --

@@ -44,6 +44,7 @@ SIGNATURES = {
     'yolo2_bn_leaky_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _l, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_pool_fin': [_p, _p, _i, _p, _p, _p, _p, _p, ctypes.c_double, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _l, _i, _f, _f, _p, _l, _i, _p],
+    'yolo2_first_layer_wgrad_bn': [_p, _p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_pool_bwd_apply_fin': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p, _l, _i, _p],
     'yolo2_bn_leaky_bwd_reduce_part': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _l, _i, _f, _f, _i, _p],
     'yolo2_bn_leaky_pool_bwd_reduce_part': [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _i, _p],

@@ -23,6 +23,9 @@
 // ---------------------------------------------------------------------------------------------------
 // shared staging: halo rows h-1, h, h+1, pixels w0-1 .. w0+32 of image b, 8 channels per pixel
 // ---------------------------------------------------------------------------------------------------
+template <int N> struct IdxPackFirst;                     // N arg-max code bytes as one integer
+template <> struct IdxPackFirst<8> { typedef unsigned long long type; };
+template <> struct IdxPackFirst<4> { typedef unsigned type; };
 template <typename T> struct First {
     static constexpr int PXB = 8 * sizeof(T);              // bytes per halo pixel (16 bf16 / 32 f32)
     static constexpr int HPIECES = PXB / 16;               // DMA pieces per halo row (64 lanes x 16 B = 1 KiB)
@@ -459,7 +462,248 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T *__restri
                     float v = 0.f;
 #pragma unroll
                     for (int w = 0; w < 4; ++w) v += red[((w * 3 + rt) * 16 + r) * 64 + lane];
+#ifdef Y2FIRST_ABL_NOATOMIC
+                    if (v == 123.456f) dW[0] = v;
+#else
                     unsafeAtomicAdd(dW + ((long)tap * Cin + c) * 32 + n, v);
+#endif
+                }
+            }
+    }
+}
+
+#ifdef Y2FIRST_EXPERIMENTS
+#define Y2F_ABL(bit) (abl & (bit))      // timing ablations (wrong results): 1 no BN arithmetic, 2 no transpose reads / MFMAs, 4 no y / dP / code loads, 8 no halo DMA
+#else
+#define Y2F_ABL(bit) 0
+#endif
+// ---------------------------------------------------------------------------------------------------
+// filter gradient with the image layer's BN / leaky / pool backward applied on the way in (round 6)
+// ---------------------------------------------------------------------------------------------------
+// conv0's gradient tensor dY (416 x 416 x 32: 177 MB at batch 16) was written by bn_bwd_apply_fin_kernel<T, true> (72 us) for exactly one reader, the
+// kernel above (56 us).  Here it never leaves the CU: a wave stages, next to its input halo, the RAW forward output y of its 32-pixel row segment and the
+// 16 pooled gradients + arg-max bytes over it (LDS-DMA), turns y into dy IN PLACE in LDS -- the arithmetic of bn_bwd_apply_fin_kernel, element for
+// element, rounded to T like the stored tensor was -- and runs the same transpose-read MFMA loop on it.  The workgroup's prologue folds the partial
+// rows of the reduction pass into dgamma / dbeta like bn_bwd_apply_fin_kernel's (workgroup 0 writes them).  Replaces reference train.py:70-80's
+// gradient of model/yolo2/inference.py:62-66 (conv0's slim.batch_norm + leaky_relu + max_pool2d) w.r.t. the filter: 405 + 221 MB of traffic -> 270 MB.
+template <typename T>
+__global__ __launch_bounds__(256, 3) void conv_first_wgrad_bn_kernel(const T *__restrict__ X, unsigned x_bytes, const T *__restrict__ Y, const T *__restrict__ dP, int lddp,
+                                                                  const unsigned char *__restrict__ idx, const float *__restrict__ mean, const float *__restrict__ var,
+                                                                  const float *__restrict__ gamma, const float *__restrict__ beta, const float *__restrict__ part, int rows,
+                                                                  long plane, float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dW, int B, int H, int W,
+                                                                  int Cin, int units, float eps, float alpha, float *__restrict__ zero, long zero_vec4, int abl) {
+    constexpr int PXB = First<T>::PXB, HALO = First<T>::HALO;
+    constexpr int N = 16 / (int)sizeof(T);                   // values per 16-byte chunk (8 / 4)
+    constexpr int YROWB = 32 * sizeof(T);                    // y / dy bytes per pixel (64 / 128)
+    constexpr int CH = YROWB / 16;                           // chunks per pixel (4 / 8)
+    constexpr int NIT = 32 * CH / 64;                        // (pixel, chunk) pairs per lane and segment (2 / 4)
+    constexpr int DYB = 32 * YROWB;                          // the segment's dy image (2 / 4 KB), one per wave: written and read by that wave only
+    constexpr int SLOT = 2 * HALO + DYB;                     // two input halos (the next segment's streams in under this one's arithmetic) + dy
+    constexpr int RED = 4 * 3 * 16 * 64 * 4;                 // cross-wave reduction scratch (reuses the staging area)
+    constexpr int SMEM = 4 * SLOT > RED ? 4 * SLOT : RED;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+    __shared__ float cst[2][32];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *my = smem + wave * SLOT;
+    unsigned char *const ys = my + 2 * HALO;
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(X), 0, x_bytes, 0x00020000);
+    const int SW = (W + 31) / 32, OH = H >> 1, OW = W >> 1;
+    const int chunk = lane % CH;                             // 64 % CH == 0: a lane keeps its channel chunk in every iteration
+    typedef typename IdxPackFirst<N>::type pack_t;
+
+    // y, pooled gradient and arg-max codes of a segment go straight to registers, one segment ahead; only the halo and dy need LDS (8 KB per wave)
+    struct Pre { Vec16<T> y[NIT], d[NIT]; pack_t p[NIT]; };
+    auto fetch = [&](Pre &r, int b, int h, int w0) {
+        if (Y2F_ABL(4)) return;
+        const long row = ((long)b * H + h) * W + w0, prow = ((long)b * OH + (h >> 1)) * OW + (w0 >> 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int px = (it * 64 + lane) / CH;
+            const bool ok = w0 + px < W;
+            const long m = ok ? row + px : row, pm = ok ? prow + (px >> 1) : prow;        // (clamped: the values of a dead pixel are never used)
+            r.y[it] = ld16(Y + m * 32 + chunk * N);
+            r.d[it] = ld16(dP + pm * lddp + chunk * N);
+            r.p[it] = *reinterpret_cast<const pack_t *>(idx + pm * 32 + chunk * N);
+        }
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    int stride, u, uend;
+    y2_first_band(units, wave, stride, u, uend);      // contiguous unit bands per XCD (see conv_first_fwd_kernel)
+    auto decode = [&](int uu, int &b, int &h, int &w0) { w0 = (uu % SW) * 32; int t = uu / SW; h = t % H; b = t / H; };
+    int cb = 0, ch = 0, cw0 = 0;
+    Pre cur, nxt;
+    if (u < uend) {
+        decode(u, cb, ch, cw0);
+        if (!Y2F_ABL(8)) stage_halo<T>(rsrcX, my, cb, ch, cw0, H, W, lane);       // in flight under the prologue
+        fetch(cur, cb, ch, cw0);
+    }
+
+    // ---- dgamma / dbeta from the partial rows [2][rows][32] (f64 like slice_partial_sums): thread = (plane, 16 row groups, four channels): 16-byte
+    // loads, rows / 16 independent ones per thread (one thread per (plane, channel, row quarter) walked 128 rows one 4-byte load at a time: 30 us of
+    // prologue in front of every workgroup)
+    {
+        __shared__ double psum[2][16][32];
+        const int pl = threadIdx.x >> 7, rg = (threadIdx.x >> 3) & 15, cq = threadIdx.x & 7;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        const float *pp = part + (long)pl * plane + cq * 4;
+#pragma unroll 4
+        for (int r = rg; r < rows; r += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + (long)r * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += (double)v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) psum[pl][rg][cq * 4 + j] = a[j];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int pl2 = threadIdx.x >> 5, c2 = threadIdx.x & 31;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += psum[pl2][k][c2];
+            const float v = (float)t;
+            cst[pl2][c2] = v;
+            if (blockIdx.x == 0) (pl2 ? dbeta : dgamma)[c2] = v;
+        }
+        __syncthreads();
+    }
+    if (zero) {
+        const long nthreads = (long)gridDim.x * 256;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < zero_vec4; i += nthreads) reinterpret_cast<f32x4 *>(zero)[i] = z;
+    }
+    // per-channel constants of this lane's chunk.  bn_bwd_apply_fin_kernel computes dy = (ga inv) (g - dbeta / M - xh dgamma / M) with xh = (y - mu) inv,
+    // z = (y - mu)(inv ga) + bt, g = z >= 0 ? da : alpha da; here the same value as two multiply-adds on four constants per channel (32 registers instead
+    // of 48 -- the difference between two and three waves per SIMD):  z = y A + o,  dy = da (z >= 0 ? A : alpha A) + (y Bc + Cc)
+    const float invM = 1.0f / (float)((long)B * H * W);
+    float cA[N], cAa[N], cO[N], cB[N], cC[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int c = chunk * N + j;
+        const float mu = mean[c], inv = 1.0f / sqrtf(var[c] + eps);
+        cA[j] = gamma[c] * inv;
+        cAa[j] = alpha * cA[j];
+        cO[j] = beta[c] - mu * cA[j];
+        cB[j] = -cA[j] * inv * (cst[0][c] * invM);
+        cC[j] = -cA[j] * (cst[1][c] * invM) - cB[j] * mu;
+    }
+
+    const int g = lane >> 4, t16 = lane & 15;
+    int st = 0;
+    for (; u < uend; u += stride) {
+        // everything issued an iteration ago has landed: this segment's halo (LDS-DMA) and registers.  (One wait for all of it: a counted wait would
+        // have to rely on the order hipcc leaves the register loads and the DMA in.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int un = u + stride;
+        int nb = 0, nh = 0, nw0 = 0;
+        if (un < uend) {
+            decode(un, nb, nh, nw0);
+            if (!Y2F_ABL(8)) stage_halo<T>(rsrcX, my + (st ^ 1) * HALO, nb, nh, nw0, H, W, lane);
+            fetch(nxt, nb, nh, nw0);
+        }
+        const unsigned char *hs = my + st * HALO;
+        // ---- y -> dy (pixels beyond the row's end get zeros), rounded to T into this wave's dy image
+        {
+            const int rp2 = 2 * (ch & 1);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int px = (it * 64 + lane) / CH;
+                const int kk = rp2 + (px & 1);
+                const bool live = cw0 + px < W;
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float yv = cur.y[it].get(j);
+                    const bool sel = (int)((cur.p[it] >> (8 * j)) & 3) == kk;          // this pixel is its window's arg-max in channel j
+                    const float z = yv * cA[j] + cO[j];
+                    float coef = z >= 0.f ? cA[j] : cAa[j];
+                    coef = sel ? coef : 0.f;
+                    const float v = cur.d[it].get(j) * coef + (yv * cB[j] + cC[j]);
+                    o.set(j, live ? (Y2F_ABL(1) ? yv : v) : 0.f);
+                }
+                *reinterpret_cast<Vec16<T> *>(ys + px * YROWB + chunk * 16) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (Y2F_ABL(2)) {
+        } else if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 bfrag, afrag[3];
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int px = ks * 16 + 8 * (g >> 1) + 4 * r + (t16 >> 2);     // pixel row this lane addresses
+                    {
+                        const unsigned char *p = ys + px * YROWB + (16 * (g & 1) + 4 * (t16 & 3)) * 2;
+                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+                        bf16x4 q = __builtin_bit_cast(bf16x4, v);
+                        bfrag[4 * r] = q[0]; bfrag[4 * r + 1] = q[1]; bfrag[4 * r + 2] = q[2]; bfrag[4 * r + 3] = q[3];
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 3; ++rt) {
+                        const int row = 32 * rt + 16 * (g & 1) + 4 * (t16 & 3);       // first of the 4 (tap, channel) rows this lane addresses
+                        int tap = row >> 3;
+                        if (tap > 8) tap = 8;                                          // rows 72..95: discarded at the end
+                        const unsigned char *p = hs + (tap / 3) * First<T>::HROWB + (px + tap % 3) * PXB + (row & 7) * 2;
+                        s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
+                        bf16x4 q = __builtin_bit_cast(bf16x4, v);
+                        afrag[rt][4 * r] = q[0]; afrag[rt][4 * r + 1] = q[1]; afrag[rt][4 * r + 2] = q[2]; afrag[rt][4 * r + 3] = q[3];
+                    }
+                }
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[rt], bfrag, acc[rt], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int px = ks * 2 + (lane >> 5);
+                const float bv = *reinterpret_cast<const float *>(ys + px * YROWB + (lane & 31) * 4);
+#pragma unroll
+                for (int rt = 0; rt < 3; ++rt) {
+                    const int row = 32 * rt + (lane & 31);
+                    int tap = row >> 3;
+                    if (tap > 8) tap = 8;
+                    const float av = *reinterpret_cast<const float *>(hs + (tap / 3) * First<T>::HROWB + (px + tap % 3) * PXB + (row & 7) * 4);
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rt], 0, 0, 0);
+                }
+            }
+        }
+        cb = nb; ch = nh; cw0 = nw0;
+        cur = nxt;
+        st ^= 1;
+    }
+
+    // combine the 4 waves through LDS (the staging slots are dead now), then one atomic per element per workgroup
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(smem);            // [4 waves][3 tiles][16 regs][64 lanes] = 48 KiB
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 3 + rt) * 16 + r) * 64 + lane] = acc[rt][r];
+    __syncthreads();
+    if (wave == 0) {
+        const int n = lane & 31;
+#pragma unroll
+        for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);    // (tap, channel)
+                const int tap = row >> 3, c = row & 7;
+                if (tap < 9 && c < Cin) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += red[((w * 3 + rt) * 16 + r) * 64 + lane];
+#ifdef Y2FIRST_ABL_NOATOMIC
+                    if (v == 123.456f) dW[0] = v;
+#else
+                    unsafeAtomicAdd(dW + ((long)tap * Cin + c) * 32 + n, v);
+#endif
                 }
             }
     }
@@ -493,6 +737,40 @@ int y2_first_layer_wgrad(const void *X, const void *dY, float *dW, int B, int H,
 
 // ---- fused image layer (conv_first_pool_kernel): host side.  P: image [B,H,W,8] (3 real channels), F: forward filter operand [32][72]
 static bool first_pool_ok(int B, int H, int W) { return B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0; }
+// filter gradient of the image layer straight from its pooled output gradient (conv_first_wgrad_bn_kernel): include/yolo2_hip.h
+extern "C" int yolo2_first_layer_wgrad_bn(const void *X, const void *Y, const void *dP, int lddp, const unsigned char *idx, const float *mean, const float *var,
+                                          const float *gamma, const float *beta, const float *part, int rows, long plane, float *dgamma, float *dbeta, float *dW,
+                                          int B, int H, int W, int Cin, float eps, float alpha, float *zero, long zero_floats, int dtype, void *stream) {
+    Y2_CHECK_ARG(X && Y && dP && idx && mean && var && gamma && beta && part && dgamma && dbeta && dW && rows >= 1 && lddp >= 32 && Cin >= 1 && Cin <= 8 &&
+                 first_pool_ok(B, H, W) && (dtype == YOLO2_F32 || dtype == YOLO2_BF16));
+    Y2_CHECK_ARG(plane >= (long)rows * 32 && zero_floats >= 0 && zero_floats % 4 == 0 && (zero || zero_floats == 0) && ((uintptr_t)zero & 15) == 0);
+    const long zero_vec4 = zero_floats / 4;
+    if (zero_vec4 == 0) zero = nullptr;
+    const size_t esz = dtype == YOLO2_BF16 ? 2 : 4;
+    const size_t M = (size_t)B * H * W;
+    Y2_CHECK_ARG(M * 32 * esz < (1ull << 32) && (M / 4) * (size_t)lddp * esz < (1ull << 32));
+    Y2_CHECK_ARG(((uintptr_t)X & 15) == 0 && ((uintptr_t)Y & 15) == 0 && ((uintptr_t)dP & 15) == 0 && ((uintptr_t)idx & 15) == 0 && (lddp * esz) % 16 == 0 &&
+                 ((uintptr_t)part & 15) == 0 && plane % 4 == 0);
+    const int units = B * H * ((W + 31) / 32);
+    // two workgroups per CU: measured 80 us against 91 with three (768 workgroups; every workgroup's prologue reads all partial rows) -- batch 16, 416 x 416
+    static const int gmax = y2_env_int("YOLO2_FIRST_WGRAD_GRID", 512);
+#ifdef Y2FIRST_EXPERIMENTS
+    static const int abl = y2_env_int("YOLO2_FIRST_ABL", 0);
+#else
+    const int abl = 0;
+#endif
+    const int grid = units / 4 + 8 < gmax ? (units / 4 + 8) / 8 * 8 : gmax;      // (a multiple of 8: one band of units per XCD)
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == YOLO2_BF16)
+        conv_first_wgrad_bn_kernel<bf16><<<grid, 256, 0, st>>>((const bf16 *)X, (unsigned)(M * 8 * 2), (const bf16 *)Y, (const bf16 *)dP, lddp, idx, mean, var, gamma, beta,
+                                                               part, rows, plane, dgamma, dbeta, dW, B, H, W, Cin, units, eps, alpha, zero, zero_vec4, abl);
+    else
+        conv_first_wgrad_bn_kernel<float><<<grid, 256, 0, st>>>((const float *)X, (unsigned)(M * 8 * 4), (const float *)Y, (const float *)dP, lddp, idx, mean, var, gamma, beta,
+                                                                part, rows, plane, dgamma, dbeta, dW, B, H, W, Cin, units, eps, alpha, zero, zero_vec4, abl);
+    Y2_CHECK_LAUNCH();
+    return YOLO2_OK;
+}
+
 template <int MODE>
 static int first_pool_launch(const void *P, const void *F, void *Out, unsigned char *idx, const void *dP, int lddp, float *part, int B, int H, int W, int ldo,
                              const Y2FirstBn &bn, int dtype, hipStream_t st) {

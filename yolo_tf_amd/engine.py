@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from . import ops
+from . import ops, _lib
 from .graph import pad8
 
 BN_EPS = 1e-5        # slim.batch_norm(epsilon=1e-5)   model/yolo2/inference.py:63
@@ -244,6 +244,7 @@ class Engine(object):
         # image layer recomputed inside its consumers instead of stored: 'infer' (default: detect only -- batch 256: 12.5 -> 11.3 ms),
         # '1' (training too: measured neutral, the recomputing backward kernels are VALU-bound -- profiles/r03_first_layer_fused.md), '0' never
         self.fuse_first = os.environ.get('YOLO2_FUSE_FIRST', 'infer')
+        self.fuse_first_wgrad = os.environ.get('YOLO2_FUSE_FIRST_WGRAD', '1') != '0'
         self._bz_pending = {}                                    # producer layer -> (buffer, rows): BN-backward sums waiting for their apply pass
         self._fin_rows_limit = {}
         # scratch sizes come from the library's own queries (include/yolo2_hip.h yolo2_*_workspace_bytes)
@@ -680,6 +681,7 @@ class Engine(object):
                 M = B * out.h * out.w
                 cout, k = op['cout'], op['ksize']
                 ldy = pad8(cout)
+                wgrad_done = False
                 gob, ldgo = self.gact[out]
                 xb, ldx = self.act[x]
                 if op['bn']:
@@ -732,7 +734,14 @@ class Engine(object):
                     elif pfin is not None:
                         own = pfin[3] if len(pfin) > 3 else -1
                         zbuf, zn = self.parts.take_to_zero(own)
-                        if pool is not None:
+                        if pool is not None and self._first_wgrad_fused(op, lddp):
+                            # image layer, stored-output path: the BN / leaky / pool backward apply runs inside the filter gradient (its 177 MB output
+                            # gradient had one reader; csrc/conv_first.hip conv_first_wgrad_bn_kernel)
+                            ops.first_layer_wgrad_bn(xb, yb, dpb, lddp, st['pool_idx'], st['mean'], st['var'], gamma, beta, pfin[0], pfin[1], pfin[2],
+                                                     dgam, dbet, self.gvar[op['weights'].name], B, x.h, x.w, op['cin'], BN_EPS, LEAKY_ALPHA, zbuf, zn)
+                            self._l2(op)
+                            wgrad_done = True
+                        elif pool is not None:
                             ops.bn_leaky_pool_bwd_apply_fin(dpb, lddp, st['pool_idx'], yb, st['mean'], st['var'], gamma, beta, pfin[0], pfin[1], pfin[2],
                                                             dgam, dbet, dy, B, out.h, out.w, cout, BN_EPS, LEAKY_ALPHA, zbuf, zn)
                         else:
@@ -764,7 +773,9 @@ class Engine(object):
                     ops.bias_grad(dy, ldy, self.gvar[op['biases'].name], self.ws, M, cout)
                     ring = False
                 done = None
-                if side is not None and M <= self.overlap_max_m:
+                if wgrad_done:
+                    pass
+                elif side is not None and M <= self.overlap_max_m:
                     ready = torch.cuda.Event()
                     ready.record(main)
                     side.wait_event(ready)
@@ -870,6 +881,14 @@ class Engine(object):
         return (op['bn'] and x in self.graph.inputs.values() and op['ksize'] == 3 and op['cin'] == 3 and self.act[x][1] == 8 and op['cout'] == 32
                 and out in self.fused_pool and self.act[self.fused_pool[out]['out']][1] >= 32 and x.h % 2 == 0 and x.w % 2 == 0
                 and (not self.training or self.fuse_bn_stats))
+
+    def _first_wgrad_fused(self, op, lddp):
+        """Image layer on the stored-output path: filter gradient with the BN / leaky / pool backward apply inside (YOLO2_FUSE_FIRST_WGRAD=0: the two
+        launches, A/B)."""
+        x, out = op['x'], op['out']
+        return (self.fuse_first_wgrad and op['bn'] and x in self.graph.inputs.values() and op['ksize'] == 3 and op['cin'] <= 8 and self.act[x][1] == 8
+                and op['cout'] == 32 and out in self.fused_pool and lddp >= 32 and lddp % 8 == 0 and x.h % 2 == 0 and x.w % 2 == 0
+                and 'yolo2_first_layer_wgrad_bn' not in _lib.MISSING)
 
     def _fin_limit(self, C):
         """Most partial rows a reduce_part launch may leave for a *_fin consumer with C channels (0: the shape does not qualify)."""

@@ -165,6 +165,14 @@ def bn_leaky_pool_bwd_apply_fin(dP, lddp, idx, Y, mean, var, gamma, beta, part, 
          ptr(dgamma), ptr(dbeta), ptr(dY), B, H, W, C, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
 
 
+def first_layer_wgrad_bn(X, Y, dP, lddp, idx, mean, var, gamma, beta, part, rows, plane_stride, dgamma, dbeta, dW, B, H, W, Cin, eps, alpha,
+                         zero=None, zero_floats=0):
+    """Image layer: ``bn_leaky_pool_bwd_apply_fin`` + ``conv2d_wgrad`` in one launch (the layer's output gradient never reaches HBM)."""
+    z, zn = _zero_args(zero, zero_floats)
+    call('yolo2_first_layer_wgrad_bn', ptr(X), ptr(Y), ptr(dP), lddp, ptr(idx), ptr(mean), ptr(var), ptr(gamma), ptr(beta), ptr(part), rows, plane_stride,
+         ptr(dgamma), ptr(dbeta), ptr(dW), B, H, W, Cin, eps, alpha, z, zn, dtype_code(Y.dtype), _stream())
+
+
 def bn_leaky_bwd_reduce_part(dA, ldda, Y, mean, var, gamma, beta, ws, rows_limit, M, C, eps, alpha):
     """-> number of partial rows left in ``ws`` ([2][rows][C] f32)."""
     rows = ctypes.c_int(0)
