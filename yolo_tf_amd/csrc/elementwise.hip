@@ -227,8 +227,38 @@ struct RowMap {  // fixed channel group per thread, rows strided
 // sums the nb partials per channel in f64 and applies the finalisation (mean/var, dgamma/dbeta,
 // bias gradient).  (A first version used f64 atomics on 2*C addresses: 2048 blocks contending on
 // 64 addresses made the reductions 40 % of the training step.)
+// (round 6) With 4 .. 32 threads per row -- 32 .. 256 channels in bf16 -- the row slots of a wave meet on the VALU first (common.h y2_lane_group_sum: the
+// lanes that share lane % tpr) and only the four waves' sums go through LDS.  The general path below leaves the whole sum to `tpr` threads, rpp serial
+// LDS reads per value: with 32 channels that is 4 threads x 1024 dependent reads, ~15 us at the end of every launch (measured: conv0's BN-backward
+// reduction took 33 us for 88 MB, its 128-channel sibling 19 us for 22 MB).
+template <int N, int K, int G>
+__device__ __forceinline__ void block_colsum_store_g(const float (&part)[K][N], int C, float *out, int nb) {
+    __shared__ float redw[K][4][32][N];     // [quantity][wave][channel group][value]: 8 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float v = y2_lane_group_sum<G>(part[k][j]);
+            if (lane < G) redw[k][wave][lane][j] = v;
+        }
+    __syncthreads();
+    if (threadIdx.x < G) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                out[((long)k * nb + blockIdx.x) * C + threadIdx.x * N + j] =
+                    (redw[k][0][threadIdx.x][j] + redw[k][1][threadIdx.x][j]) + (redw[k][2][threadIdx.x][j] + redw[k][3][threadIdx.x][j]);
+    }
+}
 template <int N, int K>
 __device__ __forceinline__ void block_colsum_store(const float (&part)[K][N], const RowMap &rm, int C, float *out, int nb) {
+    // (tpr * rpp == 256 for these: every thread is active)
+    if (rm.tpr == 4) return block_colsum_store_g<N, K, 4>(part, C, out, nb);
+    if (rm.tpr == 8) return block_colsum_store_g<N, K, 8>(part, C, out, nb);
+    if (rm.tpr == 16) return block_colsum_store_g<N, K, 16>(part, C, out, nb);
+    if (rm.tpr == 32) return block_colsum_store_g<N, K, 32>(part, C, out, nb);
     __shared__ float red[K][256][N];  // N<=8, K<=2 -> 16 KB
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -922,17 +952,22 @@ __device__ __forceinline__ void slice_partial_sums(const float *__restrict__ par
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float *p = part + (long)k * plane + sm.c0 + l4 * 4;
+        // four independent 16-byte loads in flight per thread, the last group included (a row beyond the end loads row g again with weight 0): the
+        // prologue is a chain of L2 latencies in front of the whole workgroup -- 44 rows over 8 row groups are two rounds instead of four
         double s[4] = {0.0, 0.0, 0.0, 0.0}, t[4] = {0.0, 0.0, 0.0, 0.0};
-        int r = g;
-        for (; r + ng < rows; r += 2 * ng) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (long)r * C), b = *reinterpret_cast<const f32x4 *>(p + (long)(r + ng) * C);
+        for (int r = g; r < rows; r += 4 * ng) {
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s[j] += (double)a[j]; t[j] += (double)b[j]; }
-        }
-        if (r < rows) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(p + (long)r * C);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (long)(r + u * ng < rows ? r + u * ng : g) * C);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += (double)a[j];
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = r + u * ng < rows;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double x = ok ? (double)v[u][j] : 0.0;
+                    if (u & 1) t[j] += x; else s[j] += x;
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) red[k][g * sm.cs + l4 * 4 + j] = s[j] + t[j];
