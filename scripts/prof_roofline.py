@@ -17,8 +17,10 @@ from prof_summary import load          # noqa: E402
 def dominant(name):
     if 'conv3x3_pp_kernel' in name or 'conv3x3_tap_kernel' in name:       # (round 4: ping-pong tap-fused kernel; rounds 2-3: conv3x3_tap_kernel)
         return True
-    if 'conv_c64_fwd_kernel' in name or 'conv3x3_s4_kernel' in name:        # (round 6: conv2 / conv4 forward with the filter in registers; the loader / consumer member)
+    if 'conv3x3_s4_kernel' in name:                                          # (round 6: the loader / consumer member)
         return True
+    if 'conv_c64_fwd_kernel' in name:        # (round 6: conv2 / conv4 forward with the filter in registers = its 128-filter form <MODE, 4>; the 32-filter form is conv1's data gradient)
+        return bool(re.search(r'conv_c64_fwd_kernelILi\d+ELi4E|conv_c64_fwd_kernel<\d+, 4>', name))
     m = re.search(r'conv_igemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E', name)      # T, BN, WGN, NSTAGE, KS
     if m:
         return int(m.group(2)) == 128 and int(m.group(5)) == 3
