@@ -456,9 +456,6 @@ int yolo2_debug_set_pp(int grid, int sched, int min_steps, int min_share);
  * and sums its partners' partial tiles and runs the epilogue, so it gets up to that many fewer K steps (csrc/conv_pp.hip "cost-balanced shares");
  * 0 = equal K-step shares.  The library clamps it below half a share.  YOLO2_PP_CV sets the initial value. */
 int yolo2_debug_set_pp_cost(int cv);
-/* distributed fix-up of the ping-pong kernel's stream-K launches (1): every contributor of a tile parks its partial segment and finishes a share of the
- * tile; 0 (default: measured faster) = the workgroup that holds K step 0 finishes it alone.  A/B and tests only. */
-int yolo2_debug_set_pp_dfx(int on);
 /* tests: the stream-K owners' wait limit in microseconds (0 = the default, 2 s); unclamped != 0 lets a grid forced through yolo2_debug_set_pp
  * exceed the number of K steps -- a partition no owner can be served by, which must end in yolo2_check_async_errors() == YOLO2_E_LAUNCH */
 int yolo2_debug_set_streamk_wait_us(int us, int unclamped);

@@ -58,7 +58,7 @@ def short(plan, keys):
     return '/'.join(str(plan[k]) for k in keys)
 
 
-ws = torch.zeros(1024 + 2 * 256 * 256 * 128, dtype=torch.float32, device="cuda")      # two slots per workgroup: the distributed fix-up (YOLO2_PP_DFX=0: the classic hand-off)
+ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
 tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
 f3 = {'fwd': [0.0, 0.0], 'dgrad': [0.0, 0.0]}      # [flops, us] of the 3x3 launches with > 64 filters (the roofline kernel set)
 print('%-8s %12s %12s %12s   (us | TFLOP/s)  batch %d  %s' % ('layer', 'fwd', 'dgrad', 'wgrad', B, tag))

@@ -14,7 +14,7 @@ if os.environ.get('LAYERS'):
 B = int(os.environ.get('B', 16))
 DGRAD = os.environ.get('DGRAD', '0') == '1'
 T = torch.bfloat16
-ws = torch.zeros(1024 + 2 * 256 * 256 * 128, dtype=torch.float32, device="cuda")      # two slots per workgroup: the distributed fix-up (YOLO2_PP_DFX=0: the classic hand-off)
+ws = torch.zeros(1024 + 256 * 256 * 128, dtype=torch.float32, device='cuda')
 NAMES = ['prologue', 'K loop', 'park', 'flag wait', 'partner read', 'drain', 'staging', 'store issue', 'final publish', 'segments', 't_begin', 't_end', 'store ack']
 lib = _lib.load()
 

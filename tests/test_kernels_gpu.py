@@ -357,22 +357,20 @@ TAP_SHAPES = [(16, 13, 13, 512, 1024), (16, 26, 26, 256, 512), (9, 52, 52, 128, 
               (16, 55, 55, 128, 128), (16, 13, 13, 3072, 1024), (16, 13, 13, 1024, 512), (16, 26, 26, 512, 256)]
 # variant -> (yolo2_debug_set_igemm_tap mode, ping-pong grid (1 stream-K / 2 one workgroup per tile), ping-pong SCHED (-1 = the default))
 # s4 / s4_tiles: the loader / consumer member of the family (conv_s4.hip: four computing waves of 128 x 64 + four loader waves; plan word waves == 4)
-# (mode, forced grid mode, LOAD-phase order, distributed fix-up): 'pp' = stream-K with round 5's hand-off (the owner of a tile finishes it alone: a workspace
-# of one slot per workgroup), 'pp_dfx' = every contributor parks and finishes a share of the tile (two slots per workgroup: the product's workspace)
-TAP_VARIANTS = {'pp': (2, 1, -1, False), 'pp_dfx': (2, 1, -1, True), 'pp_tiles': (2, 2, -1, False), 's4': (3, 1, -1, False), 's4_tiles': (3, 2, -1, False)}
+TAP_VARIANTS = {'pp': (2, 1, -1), 'pp_tiles': (2, 2, -1), 's4': (3, 1, -1), 's4_tiles': (3, 2, -1)}
 _TAP_ORACLE = {}       # shape -> oracle convolution (the same for every variant and epilogue: minutes of CPU time when recomputed 12 times)
 
 
 TAP_EPILOGUES = ['plain', 'bias_leaky', 'bn_stats', 'dgrad_bn']
 # stream-K: every shape x every epilogue.  One workgroup per tile: the bench shapes the launch rule gives a tile grid (26x26 256->512 forward,
 # 52x52 / 55x55 data gradients).
-TAP_CASES = [(s_, v_, e_) for v_ in ('pp', 'pp_dfx', 's4') for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
+TAP_CASES = [(s_, v_, e_) for v_ in ('pp', 's4') for e_ in TAP_EPILOGUES for s_ in TAP_SHAPES] + \
             [(s_, v_, e_) for v_ in ('pp_tiles', 's4_tiles') for e_ in ('plain', 'bn_stats', 'dgrad_bn') for s_ in (TAP_SHAPES[1], TAP_SHAPES[2], TAP_SHAPES[5])]
 # Shapes with fewer K steps than CUs (odd sizes, partial tiles, 3 and 5 chunks, H != W).  A forced stream-K grid used to leave workgroups without
 # work whose flags an owner then waited for (a hang, found by these shapes); launch_conv clamps the grid to the number of K steps
 # (green on hardware: profiles/r05_tiny_tap_shapes.txt).
 _tiny = [(3, 5, 7, 64, 72), (2, 19, 19, 128, 200), (1, 27, 28, 192, 128), (5, 10, 10, 320, 264)]
-TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_dfx', 'pp_tiles', 's4', 's4_tiles') for s_ in _tiny]
+TAP_CASES += [(s_, v_, e_) for e_ in TAP_EPILOGUES for v_ in ('pp', 'pp_tiles', 's4', 's4_tiles') for s_ in _tiny]
 # batch-normalised outputs / producer activations are stored unpadded: those epilogues only with a filter count that is a multiple of 8
 TAP_CASES = [c_ for c_ in TAP_CASES if c_[2] in ('plain', 'bias_leaky') or c_[0][4] % 8 == 0]
 
@@ -383,7 +381,7 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
     one workgroup per tile, against the per-tap kernel on the same operands -- same products, a different f32 summation order across
     stream-K segments only -- and against the oracle."""
     B, H, W, Cin, Cout = shape
-    mode, pp_grid, pp_dma, dfx = TAP_VARIANTS[variant]
+    mode, pp_grid, pp_dma = TAP_VARIANTS[variant]
     k, M = 3, B * H * W
     rng = np.random.RandomState(sum(shape) + 3)
     x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
@@ -393,13 +391,12 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
     F = torch.zeros(Cout * k * k * Cin, dtype=T, device='cuda')
     ops.filter_prep(dev(w), F, None, k, Cin, Cin, Cout, ldo, T)
     xd = dev(x, T)
-    ws = torch.full((1024 + (2 if dfx else 1) * 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
+    ws = torch.full((1024 + 256 * 256 * 128,), 3.0, dtype=torch.float32, device='cuda')
     bias = dev(rng.randn(Cout).astype(np.float32))
     out = {}
     for tap in (0, 1):
         ops.set_igemm_tap(mode if tap else 0)
         ops.set_pp(grid=pp_grid, dmapos=pp_dma, min_steps=0, min_share=0)      # every shape of this test takes the ping-pong kernel (dmapos < 0: keep the default SCHED)
-        ops.set_pp_dfx(dfx)
         try:
             O = torch.zeros(M * ldo, dtype=T, device='cuda')
             extra = None
@@ -434,15 +431,12 @@ def test_conv_tap_fused_3x3(ops, shape, variant, epilogue):
             assert (plan['stages'] == 18) == bool(tap and Cout > 64), plan
             if tap and Cout > 64:
                 assert plan['waves'] == (4 if mode == 3 else 8), plan
-                if pp_grid == 1:
-                    assert bool(plan['grid_y'] >> 16 & 1) == dfx, plan      # plan word grid_y bit 16: the distributed fix-up ran
             if tap and pp_grid == 2:
                 assert plan['grid_x'] == -(-M // 256) * -(-Cout // 128), plan
             out[tap] = (host(O).reshape(M, ldo), plan, extra)
         finally:
             ops.set_igemm_tap(2)
             ops.set_pp(grid=0, min_steps=18, min_share=24)
-            ops.set_pp_dfx(False)
     y0, y1 = out[0][0], out[1][0]
     assert np.all(y1[:, Cout:] == 0)
     assert_close(y1, y0, 8e-3, 'tap-fused vs per-tap %s %s' % (shape, epilogue))     # one bf16 ulp where the f32 sums round differently

@@ -117,7 +117,6 @@ QUERIES = {
     'yolo2_debug_set_igemm_tap': (_i, [_i]),
     'yolo2_debug_set_pp': (_i, [_i, _i, _i, _i]),
     'yolo2_debug_set_pp_cost': (_i, [_i]),
-    'yolo2_debug_set_pp_dfx': (_i, [_i]),
     'yolo2_debug_set_s4_abl': (_i, [_i]),
     'yolo2_debug_last_wgrad_plan': (_i, [ctypes.POINTER(_i)]),
     'yolo2_debug_wgrad_row_plan': (_i, [_i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),

@@ -634,17 +634,13 @@ static unsigned *ensure_pool_locked(int dev) {
     }
     return g_flag_pool[dev];
 }
-// -> the flag set of this launch; *epoch (if asked for) = a non-zero value no earlier user of the same set had (distributed fix-up of conv_pp.hip:
-// its flags, the upper half of the set, are compared with the epoch and never cleared)
-static unsigned *stream_flags(unsigned *epoch = nullptr) {
+static unsigned *stream_flags() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(g_flag_mutex);
     unsigned *pool = ensure_pool_locked(dev);
     if (!pool) return nullptr;
-    const auto c = g_flag_counter[dev]++;
-    if (epoch) { *epoch = (unsigned)(c + 1); if (*epoch == 0u) *epoch = 0x80000000u; }
-    return pool + (size_t)(c % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_STRIDE;
+    return pool + (size_t)(g_flag_counter[dev]++ % Y2_STREAM_FLAG_SETS) * Y2_STREAM_FLAG_STRIDE;
 }
 // Enqueues, on `stream`, a copy of the CURRENT device's give-up counters (one word per flag set) into caller-owned pinned host memory: the
 // asynchronous form of yolo2_check_async_errors.  A host that finds a non-zero word once the copy has completed (event / stream query) calls
@@ -851,10 +847,6 @@ static std::atomic<long> g_pp_min_share{24};
 static const int g_pp_long_share = y2_env_int("YOLO2_PP_LONG_SHARE", 26);      // (0 = round 4's rule, for the A/B)
 // cost units charged to the owner of a stream-K tile, in K steps (conv_pp.hip "cost-balanced shares"); 0 = equal K-step shares (round 5)
 static std::atomic<int> g_pp_cv{y2_env_int("YOLO2_PP_CV", 0)};
-// distributed fix-up of the ping-pong kernel's stream-K launches (conv_pp.hip): YOLO2_PP_DFX=1 / yolo2_debug_set_pp_dfx(1); the default (0) is the classic
-// hand-off -- the owner finishes its tile alone -- which measured 3.9 us per dominant launch FASTER (profiles/r06_pp_dfx.txt)
-static std::atomic<int> g_pp_dfx{y2_env_int("YOLO2_PP_DFX", 0)};
-extern "C" int yolo2_debug_set_pp_dfx(int on) { g_pp_dfx.store(on ? 1 : 0, std::memory_order_relaxed); return YOLO2_OK; }
 extern "C" int yolo2_debug_set_pp_cost(int cv) {
     if (cv < 0 || cv > 4096) { yolo2_set_error("yolo2_debug_set_pp_cost: 0 .. 4096 K steps"); return YOLO2_E_ARG; }
     g_pp_cv.store(cv, std::memory_order_relaxed);
@@ -948,12 +940,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
             // lies inside its tile, and one without work never raises it (only a forced grid on a tiny problem gets here: the rule above
             // asks for >= 10 steps per workgroup)
             if (grid > units_p && !g_sk_unclamped.load(std::memory_order_relaxed)) grid = (int)units_p;
-            unsigned epoch = 0;
-            if (grid > 0 && (sk_flags = stream_flags(&epoch)) != nullptr) {
-                // distributed fix-up (conv_pp.hip): stream-K launches of the ping-pong kernel whose workspace holds two slots per workgroup
-                const bool dfx = g_pp_dfx.load(std::memory_order_relaxed) != 0 && grid != tiles_t && tap_mode != 3 && grid <= Y2_STREAM_FLAG_WORDS / 2 &&
-                                 (size_t)grid * 2 * 256 * 128 * sizeof(float) <= ws_bytes;
-                if (!dfx) epoch = 0;
+            if (grid > 0 && (sk_flags = stream_flags()) != nullptr) {
                 const int plan_[8] = {256, 128, 8, 8, 18, 2, grid, 1};      // "stages" 18: nine taps per halo image, two phases per tap
                 for (int i_ = 0; i_ < 8; ++i_) g_last_plan[i_] = plan_[i_];
                 // partial rows: forward statistics one per (pixel tile, wave row); BN-backward sums of the ping-pong kernel one per pixel tile (its wave
@@ -963,8 +950,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
                 // waits for the flag of every workgroup inside its tile); whole-tile grids have no shares to balance
                 int cv = grid == tiles_t ? 0 : g_pp_cv.load(std::memory_order_relaxed);
                 if (cv > units_p / grid / 2) cv = (int)(units_p / grid / 2);
-                if (dfx) cv = 0;                    // (every contributor finishes a share of the tile: nothing to balance)
-                g_last_plan[7] = 1 + (cv << 8) + (dfx ? 1 << 16 : 0);      // plan word grid_y: bits 8-15 = the owner cost in use, bit 16 = distributed fix-up
+                g_last_plan[7] = 1 + (cv << 8);      // plan word grid_y: bits 8.. = the owner cost in use
                 if (tap_mode == 3) {
                     g_last_plan[2] = 4;             // plan word waves: four COMPUTING waves (+ four loaders)
                     if (y2_conv3x3_s4_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_, 1, grid,
@@ -973,7 +959,7 @@ static int launch_conv(const void *P, const void *F, const float *bias, void *O,
                     g_last_plan[2] = 8;
                 }
                 if (y2_conv3x3_pp_launch(P, p_bytes, F, f_bytes, bias, O, ws, H, W, Cp, ldp, Nf, ldo, M, NT2, bn_shift, bn_part, sk_flags, act_alpha, bz_,
-                                         /* K rotation of the stream-K tiles (profiles/r03_l2_stationary_ab.md) */ 1, grid, g_pp_dmapos.load(std::memory_order_relaxed), cv, epoch, st) == 0)
+                                         /* K rotation of the stream-K tiles (profiles/r03_l2_stationary_ab.md) */ 1, grid, g_pp_dmapos.load(std::memory_order_relaxed), cv, st) == 0)
                     return 0;
             }
         }
@@ -1157,7 +1143,7 @@ extern "C" size_t yolo2_conv2d_workspace_bytes(int B, int H, int W, int Cp, int 
     const Tune &tu = tune();
     const size_t M = (size_t)B * H * W;
     const int vec = dtype == YOLO2_BF16 ? 8 : 4;
-    size_t need = (size_t)tu.cus * 2 * 256 * 128 * sizeof(float);      // (two slots per workgroup: the distributed fix-up parks every partial segment)
+    size_t need = (size_t)tu.cus * 256 * 128 * sizeof(float);
     const long tiles = (long)cdiv((long)M, 128) * cdiv(Nf, 128);
     if (choose_ksplit((int)(tiles > (1 << 30) ? (1 << 30) : tiles), ksize * ksize * cdiv(Cp, 4 * vec), tu.target_blocks) > 1 && M * Nf * sizeof(float) > need)
         need = M * Nf * sizeof(float);

@@ -84,8 +84,7 @@ template <bool BNBWD, int HROWS, int NSB, int SCHED>
 __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
     const bf16 *__restrict__ P, unsigned p_bytes, const bf16 *__restrict__ F, unsigned f_bytes, const float *__restrict__ bias,
     bf16 *__restrict__ O, float *__restrict__ slots, int H, int W, int Cp, int ldp, int Nf, int ldo, int M, int NT,
-    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate, int cv,
-    unsigned epoch) {
+    const float *__restrict__ bn_shift, float *__restrict__ bn_part, unsigned *__restrict__ flags, float act_alpha, const Y2BnBwd bz, int k_rotate, int cv) {
     typedef bf16 T;
     constexpr int BM = Y2P_BM, BN = Y2P_BN, NW = 8, WGN = 2, WGM = 4, TM = 2, TN = 2, VEC = 8, ROWB = 128, TAPS = 9;
     constexpr int HBYTES = HROWS * 128, HB = HBYTES + 1024, RING = 2 * HB, D = NSB - 1;
@@ -152,198 +151,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
   unsigned long long ph_[Y2P_PHASES] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_tl = 0;
   if (A_PHASES) { ph_tl = wall_clock64(); ph_[10] = ph_tl; }
 #endif
-  // Distributed fix-up (round 6, `epoch` != 0).  In the classic hand-off only the workgroup that holds K step 0 of a tile finishes it: it waits for
-  // its partners, reads their parked partial tiles (2 x 128 KB at the ~100 GB/s one CU pulls) and runs the whole epilogue while the partners' CUs
-  // idle -- the launch ends 8 .. 13 us after the average workgroup (profiles/r06_pp_fixed_cost.txt).  Here EVERY contributor parks every partial
-  // segment (two slots per workgroup), raises ONE flag -- the launch's epoch: nothing is cleared -- and then finishes its share of the tiles it
-  // contributed to: contributor r of n takes the 64 x 64 wave tiles j = r, r + n, ... of the tile, one per wave, sums the n partials of that wave tile
-  // (n x 16 KB) into registers in the accumulator layout and runs the per-wave epilogue on it.  Waiting is symmetric now, but still only for work
-  // that never waits itself (every workgroup publishes before it waits), and the lowest unfinished workgroups only need workgroups at most a tile
-  // ahead: with in-order dispatch and a handful of resident workgroups the chain always moves; the wait is bounded as before.
-  // MEASURED SLOWER and not the default (profiles/r06_pp_dfx.txt: conv13 forward 41.3 -> 48.3 us, the step +100 us): the tail of a stream-K launch is
-  // a chain of latencies, not of bytes -- a workgroup with two segments pays two prologues and finishes its K steps at ~31 us where a one-segment
-  // workgroup is done at ~25; with one flag per workgroup every tile now waits for such a workgroup's LAST segment (the classic owner only needs its
-  // partners' FIRST segments and the middles), then for store acknowledgement + flag + first-byte latency again.  Kept as a tested variant.
-  const bool dfx = epoch != 0u;
-  int nfix = 0, fix_t[2] = {0, 0};
-    // ---- epilogue of one 64 x 64 wave tile: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave LDS image, 16-byte stores), with the
-    // forward statistics or the producer layer's BN-backward sums taken from the rounded values.  (lane_e, wave_e): the executing lane and wave (LDS
-    // image); (wm_e, wn_e): the wave tile inside the 256 x 128 tile at (m0, n0) it finishes -- the wave's own in the segment loop, any in the fix-up phase
-    auto epilogue = [&](f32x16 (&acc)[TM][TN], const int m0, const int n0, const int mt, const int lane_e, const int wave_e, const int wm_e, const int wn_e,
-                        const bool barriers) {
-        const bool stats = !BNBWD && bn_part != nullptr;
-        const bool bstats = BNBWD && bn_part != nullptr;
-        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave_e row) pair
-        constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
-        static_assert(NW * WROWS * WSTRIDE <= RING, "tile image fits the halo buffers");
-        static_assert(NW * WROWS * WSTRIDE <= HB + HBYTES, "the idle-DMA sink (zero KiB of halo buffer 1) lies behind the tile image");
-        float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
-        Vec16<T> yv[YG];
-        const int bz_nb = min(n0 + wn_e * TN * 32 + (lane_e % WCPR) * VEC, Nf - VEC);
-        auto bz_load_y = [&](int it0) {
-#pragma unroll
-            for (int u = 0; u < YG; ++u) {
-                const int m = min(m0 + wm_e * WROWS + ((it0 + u) * 64 + lane_e) / WCPR, M - 1);
-                yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
-            }
-        };
-        // per-column constants of both accumulator columns, requested before the drain below (their latency runs under it)
-        float bvj[TN], shj[TN];
-        bool nokj[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
-            nokj[j] = n < Nf;
-            bvj[j] = (bias && nokj[j]) ? bias[n] : 0.f;
-            shj[j] = (stats && nokj[j]) ? bn_shift[n] : 0.f;
-        }
-        // (idle DMA slots of the last steps may still be in flight: they write zeros into ring stages and the sink KiB, all behind the tile image)
-        if (BNBWD && bstats) bz_load_y(0);                    // (in flight under the staging loop)
-        if (barriers) __syncthreads();                        // every wave has finished reading the last step's operands (fix-up phase: the phase's own barrier)
-        Y2P_STAMP(5);
-        unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
-        const bool tail = m0 + BM > M;
-        // Staging: rounded tile into this wave's LDS image (+ the statistics of the rounded values).  Two copies of the 64-element loop,
-        // chosen by ONE uniform branch: the leaky ReLU of a BN-folded inference layer and the row test of the last pixel tile each cost
-        // two to three VALU per element when they are tested inside it (~10 % of the ~7 us a tile's epilogue takes).
-        auto stage_tile = [&](auto act_tag, auto tail_tag) {
-            constexpr bool ACT = decltype(act_tag)::value, TAIL = decltype(tail_tag)::value;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float bv = bvj[j], sh = shj[j];
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = i * 32 + 4 * (lane_e >> 5) + (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r] + bv;
-                        if (ACT) v = fmaxf(v, act_alpha * v);
-                        const T o = (T)v;
-                        *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane_e & 31)) * 2) = o;
-                        if (stats && (!TAIL || m0 + wm_e * WROWS + row < M)) {
-                            const float d = (float)o - sh;
-                            s1 += d;
-                            s2 += d * d;
-                        }
-                    }
-                }
-                if (stats) {
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (lane_e < 32 && nokj[j]) {
-                        const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
-                        const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                        float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
-                        if (stats_unique) { *p1 = s1; *p2 = s2; }
-                        else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
-                    }
-                }
-            }
-        };
-        if (act_alpha != 1.0f) { if (tail) stage_tile(std::true_type{}, std::true_type{}); else stage_tile(std::true_type{}, std::false_type{}); }
-        else if (tail) stage_tile(std::false_type{}, std::true_type{});
-        else stage_tile(std::false_type{}, std::false_type{});
-        Y2P_STAMP(6);
-        if (bstats) {
-            // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
-            // loop, where the 64 accumulator registers are still live -- the BN-backward instantiations then need 245 .. 256+ registers)
-            int nb_c = bz_nb;
-            asm volatile("" : "+v"(nb_c));
-#pragma unroll
-            for (int k = 0; k < VEC; k += 4) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + nb_c + k), b = *reinterpret_cast<const f32x4 *>(bz.var + nb_c + k);
-                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + nb_c + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + nb_c + k);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    cmu[k + q] = a[q];
-                    cinv[k + q] = 1.0f / sqrtf(b[q] + bz.eps);
-                    cga[k + q] = c[q];
-                    cbt[k + q] = d[q];
-                    ps[0][k + q] = ps[1][k + q] = 0.f;
-                }
-            }
-        }
-        static_assert(NIT % YG == 0, "whole groups of y vectors");
-        // (groups of YG rows, NOT unrolled across groups: fully unrolled, the eight iterations' loads were all hoisted to the top and the
-        // BN-backward variant needed more than 256 registers)
-#pragma unroll 1
-        for (int g0 = 0; g0 < NIT; g0 += YG) {
-            if (bstats && g0) bz_load_y(g0);
-#pragma unroll
-            for (int u = 0; u < YG; ++u) {
-                const int id = (g0 + u) * 64 + lane_e;
-                const int row = id / WCPR, ch = id % WCPR;
-                const int m = m0 + wm_e * WROWS + row;
-                const int n = n0 + wn_e * TN * 32 + ch * VEC;
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
-                if (m < M && n < Nf) {
-                    *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
-                    if (bstats) {
-                        const Vec16<T> y = yv[u];
-                        Vec16<T> d;
-                        d.v = __builtin_bit_cast(decltype(d.v), v);
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k) {
-                            const float xh = (y.get(k) - cmu[k]) * cinv[k];
-                            const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
-                            const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
-                            ps[0][k] += g * xh;
-                            ps[1][k] += g;
-                        }
-                    }
-                }
-            }
-        }
-        if (bstats) {
-            // (the lanes that share a channel chunk meet on the VALU: common.h y2_lane_group_sum)
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                ps[0][k] = y2_lane_group_sum<WCPR>(ps[0][k]);
-                ps[1][k] = y2_lane_group_sum<WCPR>(ps[1][k]);
-            }
-            if (!barriers) {
-                // (fix-up phase: the wave tiles of a tile are finished by different workgroups; every wave adds its own sums -- these are the launches
-                // with few pixel tiles, where same-address adds are rare)
-                const int nbw = n0 + wn_e * TN * 32 + lane_e * VEC;
-                if (lane_e < WCPR && nbw < Nf) {
-                    const int slot = mt & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                    float *p1 = bn_part + (long)slot * Nf + nbw, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nbw;
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
-                }
-            } else {
-            // The four wave rows of the tile hold sums of the SAME channels: they meet in LDS (the 7 KiB between the tile image and the idle-DMA sink) and
-            // the tile leaves ONE partial row per filter -- a quarter of the adds, and at most 169 pixel tiles instead of 676 (tile, wave row) pairs
-            // competing for the partial rows: same-address f32 atomics were 12 us of the 52 x 52 launch's 52 (profiles/r06_pp_bn_epilogue.txt)
-            static_assert(NW * WROWS * WSTRIDE + NW * WCPR * 2 * VEC * 4 <= HB + HBYTES, "reduction scratch fits between the tile image and the sink");
-            float *const red = reinterpret_cast<float *>(smem + NW * WROWS * WSTRIDE);
-            if (lane_e < WCPR) {
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) { red[(wave_e * WCPR + lane_e) * 2 * VEC + k] = ps[0][k]; red[(wave_e * WCPR + lane_e) * 2 * VEC + VEC + k] = ps[1][k]; }
-            }
-            __syncthreads();
-            const int nb = n0 + wn_e * TN * 32 + lane_e * VEC;
-            if (wm_e == 0 && lane_e < WCPR && nb < Nf) {
-#pragma unroll
-                for (int r = 1; r < WGM; ++r)
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k) {
-                        ps[0][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + k];
-                        ps[1][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + VEC + k];
-                    }
-                const int slot = mt & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
-                float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
-#pragma unroll
-                for (int k = 0; k < VEC; ++k) {
-                    if (stats_unique) { p1[k] = ps[0][k]; p2[k] = ps[1][k]; }
-                    else { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
-                }
-            }
-            }
-        }
-        Y2P_STAMP(7);
-    };
   for (bool first_seg = true;; first_seg = false) {
     if (su >= su_end) break;
     const int t = (int)(su / nk);
@@ -666,24 +473,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         const __amdgpu_buffer_rsrc_t rsrcS = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * SLOT * sizeof(float)), 0x00020000);
         const unsigned slot_lane = (unsigned)(((size_t)wave_e * (TM * TN * 16 * 64) + (size_t)lane_e * 4) * sizeof(float));
         if (A_NOHANDOFF) { if (kt_beg > 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); continue; } }
-        else if (dfx && (kt_beg > 0 || kt_end < nk)) {
-            // park this partial segment in slot 2 wx + (segments parked so far); published once, after the last segment
-            const __amdgpu_buffer_rsrc_t rsrcS2 = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * 2 * SLOT * sizeof(float)), 0x00020000);
-            const unsigned mine = (unsigned)((size_t)(2 * wx + nfix) * SLOT * sizeof(float)) + slot_lane;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 v = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrcS2, mine + ((i * TN + j) * 4 + q4) * 1024, 0, 16);
-                    }
-            fix_t[nfix & 1] = t;
-            ++nfix;
-            Y2P_STAMP(2);
-            continue;
-        }
         else if (kt_beg > 0) {
             const unsigned mine = (unsigned)((size_t)wx * SLOT * sizeof(float)) + slot_lane;
 #pragma unroll
@@ -748,8 +537,169 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         continue;
     }
-    epilogue(acc, m0, n0, mt, lane_e, wave_e, wm_e, wn_e, true);
+    // ---- epilogue: the wide-store form of conv_igemm_kernel (tile rounded into a per-wave_e LDS image, 16-byte stores), with the
+    // forward statistics or the producer layer's BN-backward sums taken from the rounded values
     {
+        const bool stats = !BNBWD && bn_part != nullptr;
+        const bool bstats = BNBWD && bn_part != nullptr;
+        const bool stats_unique = bz.stat_mask_inv == 0;       // the host found a row for every (pixel tile, wave_e row) pair
+        constexpr int WROWS = TM * 32, WROWB = TN * 32 * 2, WSTRIDE = WROWB + 16, WCPR = WROWB / 16, NIT = WROWS * WCPR / 64, YG = 4;
+        static_assert(NW * WROWS * WSTRIDE <= RING, "tile image fits the halo buffers");
+        static_assert(NW * WROWS * WSTRIDE <= HB + HBYTES, "the idle-DMA sink (zero KiB of halo buffer 1) lies behind the tile image");
+        float cmu[VEC], cinv[VEC], cga[VEC], cbt[VEC], ps[2][VEC];
+        Vec16<T> yv[YG];
+        const int bz_nb = min(n0 + wn_e * TN * 32 + (lane_e % WCPR) * VEC, Nf - VEC);
+        auto bz_load_y = [&](int it0) {
+#pragma unroll
+            for (int u = 0; u < YG; ++u) {
+                const int m = min(m0 + wm_e * WROWS + ((it0 + u) * 64 + lane_e) / WCPR, M - 1);
+                yv[u] = ld16(reinterpret_cast<const T *>(bz.Y) + (long)m * Nf + bz_nb);
+            }
+        };
+        // per-column constants of both accumulator columns, requested before the drain below (their latency runs under it)
+        float bvj[TN], shj[TN];
+        bool nokj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
+            nokj[j] = n < Nf;
+            bvj[j] = (bias && nokj[j]) ? bias[n] : 0.f;
+            shj[j] = (stats && nokj[j]) ? bn_shift[n] : 0.f;
+        }
+        // (idle DMA slots of the last steps may still be in flight: they write zeros into ring stages and the sink KiB, all behind the tile image)
+        if (BNBWD && bstats) bz_load_y(0);                    // (in flight under the staging loop)
+        __syncthreads();                                      // every wave has finished reading the last step's operands
+        Y2P_STAMP(5);
+        unsigned char *wreg = smem + wave_e * (WROWS * WSTRIDE);
+        const bool tail = m0 + BM > M;
+        // Staging: rounded tile into this wave's LDS image (+ the statistics of the rounded values).  Two copies of the 64-element loop,
+        // chosen by ONE uniform branch: the leaky ReLU of a BN-folded inference layer and the row test of the last pixel tile each cost
+        // two to three VALU per element when they are tested inside it (~10 % of the ~7 us a tile's epilogue takes).
+        auto stage_tile = [&](auto act_tag, auto tail_tag) {
+            constexpr bool ACT = decltype(act_tag)::value, TAIL = decltype(tail_tag)::value;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float bv = bvj[j], sh = shj[j];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = i * 32 + 4 * (lane_e >> 5) + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r] + bv;
+                        if (ACT) v = fmaxf(v, act_alpha * v);
+                        const T o = (T)v;
+                        *reinterpret_cast<T *>(wreg + row * WSTRIDE + (j * 32 + (lane_e & 31)) * 2) = o;
+                        if (stats && (!TAIL || m0 + wm_e * WROWS + row < M)) {
+                            const float d = (float)o - sh;
+                            s1 += d;
+                            s2 += d * d;
+                        }
+                    }
+                }
+                if (stats) {
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lane_e < 32 && nokj[j]) {
+                        const int n = n0 + (wn_e * TN + j) * 32 + (lane_e & 31);
+                        const int slot = (mt * WGM + wm_e) & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                        float *p1 = bn_part + (long)slot * Nf + n, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + n;
+                        if (stats_unique) { *p1 = s1; *p2 = s2; }
+                        else { unsafeAtomicAdd(p1, s1); unsafeAtomicAdd(p2, s2); }
+                    }
+                }
+            }
+        };
+        if (act_alpha != 1.0f) { if (tail) stage_tile(std::true_type{}, std::true_type{}); else stage_tile(std::true_type{}, std::false_type{}); }
+        else if (tail) stage_tile(std::false_type{}, std::true_type{});
+        else stage_tile(std::false_type{}, std::false_type{});
+        Y2P_STAMP(6);
+        if (bstats) {
+            // (the per-channel constants through a second opaque copy of the column index: hipcc otherwise hoists their loads above the staging
+            // loop, where the 64 accumulator registers are still live -- the BN-backward instantiations then need 245 .. 256+ registers)
+            int nb_c = bz_nb;
+            asm volatile("" : "+v"(nb_c));
+#pragma unroll
+            for (int k = 0; k < VEC; k += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(bz.mean + nb_c + k), b = *reinterpret_cast<const f32x4 *>(bz.var + nb_c + k);
+                const f32x4 c = *reinterpret_cast<const f32x4 *>(bz.gamma + nb_c + k), d = *reinterpret_cast<const f32x4 *>(bz.beta + nb_c + k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    cmu[k + q] = a[q];
+                    cinv[k + q] = 1.0f / sqrtf(b[q] + bz.eps);
+                    cga[k + q] = c[q];
+                    cbt[k + q] = d[q];
+                    ps[0][k + q] = ps[1][k + q] = 0.f;
+                }
+            }
+        }
+        static_assert(NIT % YG == 0, "whole groups of y vectors");
+        // (groups of YG rows, NOT unrolled across groups: fully unrolled, the eight iterations' loads were all hoisted to the top and the
+        // BN-backward variant needed more than 256 registers)
+#pragma unroll 1
+        for (int g0 = 0; g0 < NIT; g0 += YG) {
+            if (bstats && g0) bz_load_y(g0);
+#pragma unroll
+            for (int u = 0; u < YG; ++u) {
+                const int id = (g0 + u) * 64 + lane_e;
+                const int row = id / WCPR, ch = id % WCPR;
+                const int m = m0 + wm_e * WROWS + row;
+                const int n = n0 + wn_e * TN * 32 + ch * VEC;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(wreg + row * WSTRIDE + ch * 16);
+                if (m < M && n < Nf) {
+                    *reinterpret_cast<f32x4 *>(O + (long)m * ldo + n) = v;
+                    if (bstats) {
+                        const Vec16<T> y = yv[u];
+                        Vec16<T> d;
+                        d.v = __builtin_bit_cast(decltype(d.v), v);
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k) {
+                            const float xh = (y.get(k) - cmu[k]) * cinv[k];
+                            const float z = (y.get(k) - cmu[k]) * (cinv[k] * cga[k]) + cbt[k];
+                            const float g = z >= 0.f ? d.get(k) : bz.alpha * d.get(k);
+                            ps[0][k] += g * xh;
+                            ps[1][k] += g;
+                        }
+                    }
+                }
+            }
+        }
+        if (bstats) {
+            // (the lanes that share a channel chunk meet on the VALU: common.h y2_lane_group_sum)
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                ps[0][k] = y2_lane_group_sum<WCPR>(ps[0][k]);
+                ps[1][k] = y2_lane_group_sum<WCPR>(ps[1][k]);
+            }
+            // The four wave rows of the tile hold sums of the SAME channels: they meet in LDS (the 7 KiB between the tile image and the idle-DMA sink) and
+            // the tile leaves ONE partial row per filter -- a quarter of the adds, and at most 169 pixel tiles instead of 676 (tile, wave row) pairs
+            // competing for the partial rows: same-address f32 atomics were 12 us of the 52 x 52 launch's 52 (profiles/r06_pp_bn_epilogue.txt)
+            static_assert(NW * WROWS * WSTRIDE + NW * WCPR * 2 * VEC * 4 <= HB + HBYTES, "reduction scratch fits between the tile image and the sink");
+            float *const red = reinterpret_cast<float *>(smem + NW * WROWS * WSTRIDE);
+            if (lane_e < WCPR) {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) { red[(wave_e * WCPR + lane_e) * 2 * VEC + k] = ps[0][k]; red[(wave_e * WCPR + lane_e) * 2 * VEC + VEC + k] = ps[1][k]; }
+            }
+            __syncthreads();
+            const int nb = n0 + wn_e * TN * 32 + lane_e * VEC;
+            if (wm_e == 0 && lane_e < WCPR && nb < Nf) {
+#pragma unroll
+                for (int r = 1; r < WGM; ++r)
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k) {
+                        ps[0][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + k];
+                        ps[1][k] += red[((r * WGN + wn_e) * WCPR + lane_e) * 2 * VEC + VEC + k];
+                    }
+                const int slot = mt & ((Y2_BN_PART_ROWS - 1) ^ bz.stat_mask_inv);
+                float *p1 = bn_part + (long)slot * Nf + nb, *p2 = bn_part + (long)(Y2_BN_PART_ROWS + slot) * Nf + nb;
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    if (stats_unique) { p1[k] = ps[0][k]; p2[k] = ps[1][k]; }
+                    else { unsafeAtomicAdd(p1 + k, ps[0][k]); unsafeAtomicAdd(p2 + k, ps[1][k]); }
+                }
+            }
+        }
+        Y2P_STAMP(7);
         // the idle DMA slots have landed before this workgroup's LDS is reused (next segment) or released (kernel end); the output stores ride along
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         Y2P_STAMP(12);
@@ -760,63 +710,6 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
       __syncthreads();
       if (tid == 0) __hip_atomic_store(flags + wx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       Y2P_STAMP(8);
-  }
-  if (dfx && nfix > 0) {
-      constexpr int SLOT = BM * BN;
-      unsigned *const eflags = flags + Y2_STREAM_FLAG_WORDS / 2;       // the epoch flags live in the upper half of the set (the lower half is cleared by its consumers)
-      // publish: every wave's parked stores acknowledged, then one flag for all of this workgroup's segments.  The same barrier ends the last
-      // segment's use of LDS (the wave images of the fix-up epilogues go over the halo buffers).
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(eflags + wx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      Y2P_STAMP(8);
-      int lane_f = lane, wave_f = wave;
-      asm volatile("" : "+v"(lane_f), "+s"(wave_f));
-      const __amdgpu_buffer_rsrc_t rsrcS2 = __builtin_amdgcn_make_buffer_rsrc(slots, 0, (unsigned)((size_t)gridDim.x * 2 * SLOT * sizeof(float)), 0x00020000);
-      auto share_beg = [&](int w) { return w == 0 ? 0L : share_end(w - 1); };
-      for (int f = 0; f < nfix; ++f) {
-          const int t = fix_t[f];
-          const long tile_beg = (long)t * nk, tile_end = tile_beg + nk;
-          int a = wx, b = wx;                                         // contributors of tile t: workgroups a .. b (a holds K step 0)
-          while (share_beg(a) > tile_beg) --a;
-          while (share_end(b) < tile_end) ++b;
-          const int n = b - a + 1, r = wx - a;
-          const int j = r + wave_f * n;                               // this wave's wave tile of the tile (if any)
-          if (j >= NW) continue;
-          // (bounded waits: conv_shared.h; each wave polls for itself -- the waves of the fix-up phase never meet at a barrier)
-          for (int i = lane_f; i < n; i += 64) y2_sk_wait_epoch(eflags, a + i, epoch, flags);
-          __builtin_amdgcn_wave_barrier();
-          f32x16 accf[TM][TN];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-              for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                  for (int rr = 0; rr < 16; ++rr) accf[i][jj][rr] = 0.f;
-          const unsigned part_lane = (unsigned)(((size_t)j * (TM * TN * 16 * 64) + (size_t)lane_f * 4) * sizeof(float));
-          for (int c = a; c <= b; ++c) {
-              // contributor c parked its segment of tile t in its slot 0, unless tile t is its SECOND parked segment: c == a with a parked tail in front
-              const long cb = share_beg(c);
-              const int sidx = (c == a && cb < tile_beg && cb % nk != 0) ? 1 : 0;
-              const unsigned theirs = (unsigned)((size_t)(2 * c + sidx) * SLOT * sizeof(float)) + part_lane;
-#pragma unroll
-              for (int i = 0; i < TM; ++i)
-#pragma unroll
-                  for (int jj = 0; jj < TN; ++jj)
-#pragma unroll
-                      for (int q4 = 0; q4 < 4; ++q4) {
-                          const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcS2, theirs + ((i * TN + jj) * 4 + q4) * 1024, 0, 16));
-                          accf[i][jj][4 * q4] += v[0];
-                          accf[i][jj][4 * q4 + 1] += v[1];
-                          accf[i][jj][4 * q4 + 2] += v[2];
-                          accf[i][jj][4 * q4 + 3] += v[3];
-                      }
-          }
-          Y2P_STAMP(4);
-          const int nt = t / MT, mt = t - nt * MT;
-          epilogue(accf, mt * BM, nt * BN, mt, lane_f, wave_f, j / WGN, j % WGN, false);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (this wave's image is reused by its next fix-up tile)
-      }
   }
 #ifdef Y2P_EXPERIMENTS
   if (A_PHASES && lane == 0 && (wave == 0 || wave == 4)) {
@@ -839,10 +732,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp_kernel(
 // flat (tile, K step) space -- one per CU = stream-K; one per tile = whole tiles, no hand-off.
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, unsigned epoch, hipStream_t st) {
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, hipStream_t st) {
 #define Y2P_LAUNCH(BWDv, HRv, NSBv, SCv)                                                                                                    \
     conv3x3_pp_kernel<BWDv, HRv, NSBv, SCv><<<dim3(grid), 512, 0, st>>>((const bf16 *)P, p_bytes, (const bf16 *)F, f_bytes, bias, (bf16 *)O, ws, \
-                                                                        H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate, cv, epoch)
+                                                                        H, W, Cp, ldp, Nf, ldo, M, NT, bn_shift, bn_part, sk_flags, act_alpha, bz, k_rotate, cv)
 #define Y2P_CASE(SCv)                                                                                              \
     case SCv:                                                                                                      \
         if (W <= 27) { if (bwd) Y2P_LAUNCH(true, 312, 5, SCv); else Y2P_LAUNCH(false, 312, 5, SCv); }             \

@@ -30,24 +30,8 @@ __device__ __forceinline__ void y2_sk_wait_and_clear(unsigned *flags, int p) {
     }
     __hip_atomic_store(flags + p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // exactly one consumer per flag
 }
-// Distributed fix-up (conv_pp.hip): every contributor of a tile waits until contributor p has published under this launch's epoch.  `eflags` is the
-// upper half of the set (never cleared: the epoch of a set's next user differs), `set` the set's base (status block).  Bounded like the wait above.
-__device__ __forceinline__ void y2_sk_wait_epoch(unsigned *eflags, int p, unsigned epoch, unsigned *set) {
-    if (__hip_atomic_load(eflags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-        const unsigned cfg = __hip_atomic_load(set + Y2_STREAM_FLAG_WORDS + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long limit = cfg ? cfg : Y2_SK_DEFAULT_WAIT_TICKS, t0 = wall_clock64();
-        while (__hip_atomic_load(eflags + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > limit) {
-                __hip_atomic_fetch_add(set + Y2_STREAM_FLAG_WORDS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-}
 #else
 __device__ inline void y2_sk_wait_and_clear(unsigned *, int) {}      // (host pass of a __global__ body)
-__device__ inline void y2_sk_wait_epoch(unsigned *, int, unsigned, unsigned *) {}
 #endif
 
 // Data-gradient launches whose output IS the gradient dA of a batch-normalised producer layer (a = leaky(bn(y))) can reduce that
@@ -68,7 +52,7 @@ struct Y2BnBwd {
 // conv_pp.hip: ping-pong tap-fused 3x3 kernel (bf16, 256 x 128 tile); returns non-zero when the image is too wide for its halo buffers
 int y2_conv3x3_pp_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,
                          int ldp, int Nf, int ldo, int M, int NT, const float *bn_shift, float *bn_part, unsigned *sk_flags, float act_alpha,
-                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, unsigned epoch, hipStream_t st);
+                         const Y2BnBwd &bz, int k_rotate, int grid, int sched, int cv, hipStream_t st);
 
 // conv_s4.hip: the loader / consumer member of the same family (four computing waves of 128 x 64, four loader waves); same contract
 int y2_conv3x3_s4_launch(const void *P, unsigned p_bytes, const void *F, unsigned f_bytes, const float *bias, void *O, float *ws, int H, int W, int Cp,

@@ -363,13 +363,6 @@ def set_pp(grid=-1, dmapos=-1, min_steps=-1, min_share=-1):
     _lib.load().yolo2_debug_set_pp(int(grid), int(dmapos), int(min_steps), int(min_share))
 
 
-def set_pp_dfx(on):
-    """Distributed fix-up of the ping-pong kernel's stream-K launches on / off (A/B, tests)."""
-    if 'yolo2_debug_set_pp_dfx' in _lib.MISSING:
-        return
-    _lib.load().yolo2_debug_set_pp_dfx(1 if on else 0)
-
-
 def set_pp_cost(cv):
     """Owner cost (K steps) of the ping-pong kernel's cost-balanced stream-K partition (yolo2_debug_set_pp_cost); 0 = equal K-step shares."""
     lib = _lib.load()
