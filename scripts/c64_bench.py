@@ -76,3 +76,14 @@ for B in [int(b) for b in os.environ.get("BATCHES", "16,64").split(",")]:
         res.append('%s %.1f us (%.2f TB/s of 192 B per pixel)' % (name, t, M * 192 / t * 1e-6))
         plan = ops.last_conv_plan()
     print('YOLO2_C64=%s batch %d: conv1 forward %s   plan %s' % (os.environ.get('YOLO2_C64', '1'), B, ', '.join(res), '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))
+    # conv2 / conv4's data gradient: dY 128 channels at 104 x 104 -> dX 64 channels
+    Mw = B * 104 * 104
+    dyw = torch.randn(Mw * 128, device='cuda').to(T)
+    dxw = torch.zeros(Mw * 64, dtype=T, device='cuda')
+    ww = torch.randn(9 * 64 * 128, device='cuda') * 0.05
+    Fdw = torch.zeros(64 * 9 * 128, dtype=T, device='cuda')
+    ops.filter_prep(ww, None, Fdw, 3, 64, 64, 128, 128, T)
+    t = timed(lambda: ops.conv2d_ws(dyw, Fdw, None, dxw, ws, B, 104, 104, 128, 128, 64, 64, 3))
+    plan = ops.last_conv_plan()
+    print('YOLO2_C64=%s batch %d: conv2 / conv4 data gradient %.1f us (%.0f TFLOP/s)   plan %s' % (
+        os.environ.get('YOLO2_C64', '1'), B, t, 2.0 * Mw * 64 * 9 * 128 / t * 1e-6, '/'.join(str(plan[k]) for k in ('BM', 'BN', 'stages', 'grid_x'))))

@@ -160,6 +160,8 @@ def test_dgrad_bench_shape(ops, cname, B, name, H, cin, cout, k, bn):
         assert (plan['BM'], plan['stages'], plan['grid_x']) == (256, 18, 169), plan      # 52x52 data gradient: 169 whole tiles
     if name == 'conv1' and 'YOLO2_C64' not in os.environ:
         assert (plan['BM'], plan['BN'], plan['stages']) == (256, 32, 9), plan      # 64 -> 32 at 208 x 208: the 32-filter form of conv_c64.hip
+    if name == 'conv2_4' and B == 16 and 'YOLO2_C64' not in os.environ:
+        assert (plan['BM'], plan['BN'], plan['stages']) == (128, 64, 9), plan      # 128 -> 64 at 104 x 104: the two-channel-half form of conv_c64.hip
 
 
 @pytest.mark.parametrize('cname,B,name,H,cin,cout,k,bn', list(_cases()))

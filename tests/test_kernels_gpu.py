@@ -122,6 +122,7 @@ CONV_SHAPES = [
     (2, 9, 11, 320, 200, 3),    # five chunks; data gradient single-chunk (ldy = 200)
     (2, 12, 20, 64, 128, 3),    # 64 -> 128 channels: the persistent conv2 / conv4 kernel with the filter in registers (conv_c64.hip)
     (2, 12, 20, 64, 32, 3),     # 64 -> 32: its 32-filter form (conv1's data gradient)
+    (2, 12, 20, 128, 64, 3),    # 128 -> 64: the two-channel-half form (conv2 / conv4's data gradients)
     (1, 7, 9, 64, 128, 3),      # ... one partial tile, odd extents
     (3, 40, 33, 64, 128, 3),    # ... more tiles than one workgroup round leaves whole
 ]
@@ -679,13 +680,18 @@ def test_conv_wgrad_border_only_inputs(ops, shape, mode, which):
         assert_wgrad_exact_products(host(dW).reshape(3, 3, Cin, Cout), ref, 'wgrad border-only %s in %s %s %s' % (which, side, shape, mode))
 
 
+@pytest.mark.parametrize('chan', [(32, 64, 256), (64, 128, 128)], ids=['conv1', 'conv2_4'])      # (Cin, Cout of the LAYER, plan BM of its data gradient)
 @pytest.mark.parametrize('wgs,shape', [(3, (3, 40, 33)), (1, (2, 31, 16)), (2, (1, 9, 208)), (0, (2, 26, 27))])
-def test_conv_c64_32_filter_form_as_data_gradient(ops, wgs, shape):
+def test_conv_c64_32_filter_form_as_data_gradient(ops, wgs, shape, chan):
     """conv_c64.hip with 32 filters: the data gradient of a 32 -> 64 channel 3x3 layer (Darknet-19 conv1; reference model/yolo2/inference.py:76) is
     the forward convolution of dY (64 channels) with the flipped, transposed filters.  Every wave holds the whole operand and takes 32 positions of
-    a tile; accumulators alternate over the K steps.  Against the oracle's conv2d_dgrad; with a bias / activation the call takes the generic kernel."""
+    a tile; accumulators alternate over the K steps.  The same for a 64 -> 128 channel layer (conv2 / conv4): 128-channel dY, 64 filters -- the waves of a
+    pair take one channel half each and swap partial blocks through LDS (conv_c64_wide_kernel).  Against the oracle's conv2d_dgrad; with a bias /
+    activation the call takes the generic kernel."""
     B, H, W = shape
-    Cin, Cout, k = 32, 64, 3
+    Cin, Cout, k = chan[0], chan[1], 3
+    if W > 150 and Cout == 128:
+        pytest.skip('208-wide rows of 128 channels do not fit the two-plane ring (the layer runs at 104 x 104)')
     rng = np.random.RandomState(sum(shape) + 77)
     dy = bf16_round(rng.randn(B, H, W, Cout).astype(np.float32))
     w = bf16_round((rng.randn(k, k, Cin, Cout) / np.sqrt(k * k * Cout)).astype(np.float32))
@@ -705,8 +711,8 @@ def test_conv_c64_32_filter_form_as_data_gradient(ops, wgs, shape):
         torch.cuda.synchronize()
     finally:
         ops.set_stream_workgroups(0)
-    assert (plan['BM'], plan['BN'], plan['stages']) == (256, 32, 9), plan
-    assert (planl['BM'], planl['BN'], planl['stages']) != (256, 32, 9), planl
+    assert (plan['BM'], plan['BN'], plan['stages']) == (chan[2], Cin, 9), plan
+    assert (planl['BM'], planl['BN'], planl['stages']) != (chan[2], Cin, 9), planl
     ref = R.conv2d_dgrad(dy.astype(np.float64), w.astype(np.float64))
     got = host(dx).reshape(B, H, W, Cin).astype(np.float64)
     assert (np.abs(got - ref) <= 4e-3 * np.abs(ref) + 2e-4 * np.abs(ref).max()).all(), 'c64 32-filter dgrad %s wgs %d: %.3e' % (shape, wgs, np.abs(got - ref).max())
@@ -714,7 +720,7 @@ def test_conv_c64_32_filter_form_as_data_gradient(ops, wgs, shape):
 
 
 @pytest.mark.parametrize('which', BORDERS)
-@pytest.mark.parametrize('chan', [(32, 64, 512, 64), (64, 128, 256, 128), (64, 32, 256, 32)], ids=['c32', 'c64', 'c64n'])      # (Cin, Cout, plan BM, plan BN): conv_c32.hip / conv_c64.hip (128 and 32 filters)
+@pytest.mark.parametrize('chan', [(32, 64, 512, 64), (64, 128, 256, 128), (64, 32, 256, 32), (128, 64, 128, 64)], ids=['c32', 'c64', 'c64n', 'c64w'])      # (Cin, Cout, plan BM, plan BN): conv_c32.hip / conv_c64.hip (128 and 32 filters)
 @pytest.mark.parametrize('shape', [(2, 12, 20), (1, 7, 9), (3, 40, 33), (2, 31, 16)])
 def test_conv_c32_border_only_inputs(ops, shape, which, chan):
     """conv_c32.hip (conv1 forward, padded position index with one zero column per row and one zero row per image): an input that is non-zero

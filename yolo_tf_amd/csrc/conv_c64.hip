@@ -1,5 +1,6 @@
 // 3x3 convolution for 64-channel inputs with the FILTER IN REGISTERS, bf16, gfx950: 128 filters (Darknet-19 conv2 / conv4 forward, 104 x 104 pixels per
-// image) and 32 filters (conv1's data gradient: 64 -> 32 channels at 208 x 208).
+// image) and 32 filters (conv1's data gradient: 64 -> 32 channels at 208 x 208); at the end of the file the same recipe for 128-channel inputs and 64
+// filters (conv2 / conv4's data gradients), the K extent split over wave pairs (conv_c64_wide_kernel).
 //
 // Replaces slim.layers.conv2d of reference model/yolo2/inference.py:78,82 (conv2 / conv4: 64 -> 128, 3x3, SAME, no bias under batch_norm) and the input
 // gradient of :76 (conv1), where the generic per-tap implicit-GEMM kernel pays a prologue and an epilogue per nine K steps: 43 us for 25.5 GFLOP
@@ -327,15 +328,239 @@ __global__ __launch_bounds__(512) void conv_c64_fwd_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 128-channel inputs, 64 filters: the data gradients of conv2 / conv4 (dY 128 channels at 104 x 104 -> dX 64 channels; reference
+// model/yolo2/inference.py:78,82 under tf.gradients), as the forward convolution of dY with the flipped operand.
+// ---------------------------------------------------------------------------------------------------
+// The operand is 64 filters x 1152 k = 147 KB again, but now K is twice a wave's register budget: the eight waves are (filter group of 32) x (CHANNEL
+// HALF) x (position group).  A wave holds 32 filters x the 576 k of its 64-channel half (K order of the operand: channel chunk outermost), reads only its
+// half of every pixel row -- the ring is kept as two planes of 128-byte half rows, each in the format of the kernel above -- and ends a tile with a partial
+// sum over half of K.  The two waves of a pair then swap one 32 x 32 block each through LDS (4 KB per wave) and finish one block each: the additions, the
+// rounding and the stores are split between them as well.  128-position tiles (two planes of ring + the exchange area are exactly 160 KB at 104 x 104).
+#define C64W_TP 128
+__global__ __launch_bounds__(512) void conv_c64_wide_kernel(const bf16 *__restrict__ X, unsigned x_bytes, const bf16 *__restrict__ F, bf16 *__restrict__ O, C64Geo g) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    constexpr int TP = C64W_TP;
+    const int H = g.H, W = g.W, Mp = g.Mp;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fg = wave & 1, kh = (wave >> 1) & 1, pg = wave >> 2;      // filter group (32 of 64), channel half, position group (64 of the tile's 128)
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned P1 = (unsigned)(W + 1), H1 = (unsigned)(H + 1);
+    const int s0 = (int)blockIdx.x * g.L;
+    const int e0 = min(s0 + g.L, Mp);
+    if (s0 >= Mp) return;
+    const int RRB = g.RR * 128, NPR = g.RR >> 3;             // bytes / pieces of ONE plane
+    const int pbase = s0 - g.HLa;
+    unsigned char *const xchg = smem + 2 * RRB;             // 8 x 4 KB
+
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(X), 0, x_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void *lds_void_ptr;
+    typedef const __attribute__((address_space(3))) bf16x8 *lds_frag_ptr;
+
+    // ---- ring staging: piece j = rows 8 j .. 8 j + 7 of BOTH planes (plane p = channels 64 p .. 64 p + 63 of the row: 128 bytes, swizzled like above)
+    const int prow = lane >> 3;
+    auto stage_piece = [&](int j, int slot) {
+        const int row = j * 8 + prow;
+        const unsigned q = (unsigned)(pbase + row);
+        const unsigned R = c64_div(q, g.mP, g.sP);
+        const unsigned img = c64_div(R, g.mH, g.sH);
+        const unsigned c = q - __umul24(R, P1), r = R - __umul24(img, H1);
+        const bool ok = (q < (unsigned)Mp) & (c < (unsigned)W) & (r < (unsigned)H);
+        const unsigned m = q - R - __umul24(img, (unsigned)W);
+        const unsigned voff = ok ? m * 256u + (unsigned)((((lane & 7) ^ ((row >> 1) & 7))) << 4) : Y2_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_ptr)(smem + slot * 1024), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcX, (lds_void_ptr)(smem + RRB + slot * 1024), 16, ok ? voff + 128u : Y2_OOB, 0, 0, 0);
+    };
+    for (int j = wave; j < g.NP0; j += 8) stage_piece(j, j);
+
+    // ---- the filter into registers: four rounds (filter group, channel half) of 32 rows x 1152 bytes, staged at pitch 1168 behind the first tile's rows of
+    // plane 1 (that plane's tail and the exchange area are idle until the first tile ends), picked up by the two waves that hold that (group, half)
+    bf16x8 filt[C64_KSTEPS];
+    {
+        constexpr int FROUND = 32 * C64_FPITCH;
+        const __amdgpu_buffer_rsrc_t rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(F), 0, 64u * 2304u, 0x00020000);
+        unsigned char *const fst = smem + RRB + g.NP0 * 1024;
+#pragma unroll 1
+        for (int rd = 0; rd < 4; ++rd) {
+            const int fgr = rd & 1, khr = rd >> 1;
+            for (int p = wave; p * 1024 < FROUND; p += 8) {
+                const int pos = p * 1024 + lane * 16;
+                const int n = pos / C64_FPITCH, off = pos - n * C64_FPITCH;
+                const unsigned voff = (off < 1152 && n < 32) ? (unsigned)((32 * fgr + n) * 2304 + khr * 1152 + off) : Y2_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcF, (lds_void_ptr)(fst + p * 1024), 16, voff, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (fg == fgr && kh == khr) {
+                const unsigned a0 = y2_lds_addr(fst) + (unsigned)(c64_slot_filter(l31) * C64_FPITCH + 16 * half);
+#pragma unroll
+                for (int st = 0; st < C64_KSTEPS; ++st) filt[st] = *(lds_frag_ptr)(uintptr_t)(a0 + (unsigned)(st * 32));
+            }
+            __syncthreads();
+        }
+    }
+
+    const unsigned lds0 = y2_lds_addr(smem) + (unsigned)(kh * RRB);      // this wave's plane
+    unsigned abase[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+        const int shift = (tp / 3 - 1) * (W + 1) + (tp % 3 - 1);
+        const int row = pg * 64 + l31 + g.HLa + shift;
+        abase[tp] = (unsigned)(row * 128 + ((half ^ ((row >> 1) & 7)) << 4));
+    }
+
+    const int T = (e0 - s0 + TP - 1) / TP;
+    int pslot = g.NP0;
+    if (pslot >= NPR) pslot -= NPR;
+    unsigned tro = 0;
+    for (int t = 0; t < T; ++t) {
+        __builtin_amdgcn_s_barrier();                       // (raw: every wave's pieces of this tile have landed -- each waited for its own before its last stores)
+        const int tb = s0 + t * TP;
+        if (t + 1 < T) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {                    // the next tile's 128 new rows: 16 pieces x two planes
+                const int k = wave + 8 * u;
+                int sl = pslot + k;
+                if (sl >= NPR) sl -= NPR;
+                stage_piece(g.NP0 + t * (TP / 8) + k, sl);
+            }
+        }
+        pslot += TP / 8;
+        if (pslot >= NPR) pslot -= NPR;
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        bf16x8 fb[2][2];
+        unsigned ad[2];
+        auto load = [&](int st, int set) {
+            const int tp = st >> 2, kk = st & 3;
+            if (kk == 0) {
+                unsigned x = abase[tp] + tro;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    x = min(x, x - (unsigned)RRB);
+                    ad[i] = x + lds0;
+                    x += 4096u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[set][i] = *(lds_frag_ptr)(uintptr_t)(ad[i] ^ (unsigned)(kk * 32));
+        };
+        load(0, 0);
+#pragma unroll
+        for (int st = 0; st < C64_KSTEPS; ++st) {
+            if (st + 1 < C64_KSTEPS) load(st + 1, (st + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(filt[st], fb[st & 1][i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        // ---- the pair (same filters, same positions, the other channel half) swaps one block each: this wave keeps block kh and gives block 1 - kh
+        f32x16 keep, give;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { keep[r] = kh ? acc[1][r] : acc[0][r]; give[r] = kh ? acc[0][r] : acc[1][r]; }
+        {
+            f32x4 *const xw = reinterpret_cast<f32x4 *>(xchg + wave * 4096);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) xw[q4 * 64 + lane] = f32x4{give[4 * q4], give[4 * q4 + 1], give[4 * q4 + 2], give[4 * q4 + 3]};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const f32x4 *const xr = reinterpret_cast<const f32x4 *>(xchg + (wave ^ 2) * 4096);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = xr[q4 * 64 + lane];
+                keep[4 * q4] += v[0]; keep[4 * q4 + 1] += v[1]; keep[4 * q4 + 2] += v[2]; keep[4 * q4 + 3] += v[3];
+            }
+        }
+        // ---- epilogue of block kh: round, pack pairs, 2 x 2 exchange inside lane pairs, 16-byte stores (as in the kernel above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next tile's pieces and the previous stores
+        {
+            const bool odd = (lane & 1) != 0;
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            const unsigned q = (unsigned)(tb + pg * 64 + kh * 32 + l31);
+            const unsigned R = c64_div(q, g.mP, g.sP);
+            const unsigned c = q - __umul24(R, P1);
+            const unsigned img = c64_div(R, g.mH, g.sH);
+            const unsigned r_ = R - __umul24(img, H1);
+            const bool live = (q < (unsigned)e0) & (c < (unsigned)W) & (r_ < (unsigned)H);
+            const unsigned m = __umul24(__umul24(img, (unsigned)H) + r_, (unsigned)W) + c;
+            const unsigned moff = live ? m * 128u + (unsigned)(fg * 64 + half * 32) : 0xffffffffu;
+            unsigned pk[8];
+#pragma unroll
+            for (int qd = 0; qd < 8; ++qd) {
+                const bf16x2 o2 = {(bf16)keep[2 * qd], (bf16)keep[2 * qd + 1]};
+                pk[qd] = __builtin_bit_cast(unsigned, o2);
+            }
+            unsigned s0_[4], s1_[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned x = pk[d], y = pk[4 + d];
+                const unsigned xs = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xF, 0xF, true), ys = (unsigned)__builtin_amdgcn_mov_dpp((int)y, 0xB1, 0xF, 0xF, true);
+                s0_[d] = odd ? ys : x;
+                s1_[d] = odd ? y : xs;
+            }
+            const unsigned mo_even = (unsigned)__builtin_amdgcn_mov_dpp((int)moff, 0xA0, 0xF, 0xF, true);
+            const unsigned mo_odd = (unsigned)__builtin_amdgcn_mov_dpp((int)moff, 0xF5, 0xF, 0xF, true);
+            const unsigned lo16 = odd ? 16u : 0u;
+            if (mo_even != 0xffffffffu)
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(O) + mo_even + lo16) = u32x4{s0_[0], s0_[1], s0_[2], s0_[3]};
+            if (mo_odd != 0xffffffffu)
+                *reinterpret_cast<u32x4 *>(reinterpret_cast<unsigned char *>(O) + mo_odd + lo16) = u32x4{s1_[0], s1_[1], s1_[2], s1_[3]};
+        }
+#endif
+        tro += (unsigned)(TP * 128);
+        if (tro >= (unsigned)RRB) tro -= (unsigned)RRB;
+    }
+}
+
+// -> 0 launched, 1 the shape does not fit the LDS plan (caller takes the generic kernels)
+static int y2_c64_wide(const void *P, const void *F, void *O, int B, int H, int W, int cus, hipStream_t st) {
+    const long Mp = (long)B * (H + 1) * (W + 1);
+    if (Mp + 2 * C64W_TP >= (1L << 23) || H < 1 || W < 1 || cus < 1) return 1;
+    C64Geo g;
+    g.H = H; g.W = W; g.M = B * H * W; g.Mp = (int)Mp;
+    g.L = (int)(((Mp + cus - 1) / cus + C64W_TP - 1) / C64W_TP) * C64W_TP;
+    const int grid = (int)((Mp + g.L - 1) / g.L);
+    g.HLa = (W + 2 + 7) & ~7;
+    g.NP0 = (g.HLa + C64W_TP + W + 2 + 7) / 8;
+    g.RR = (8 * g.NP0 + C64W_TP + 63) & ~63;
+    g.shl_off = 0;
+    const size_t plane = (size_t)g.RR * 128, lds = 2 * plane + 8 * 4096;
+    // room for a filter round (32 rows at pitch 1168 = 37 pieces) behind the first tile's rows of plane 1
+    if (lds > 160 * 1024 || (plane - (size_t)g.NP0 * 1024) + 8 * 4096 < 37 * 1024) return 1;
+    y2_magic_u32((unsigned)(W + 1), &g.mP, &g.sP);
+    y2_magic_u32((unsigned)(H + 1), &g.mH, &g.sH);
+    static std::atomic<size_t> lds_set[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > lds_set[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute((const void *)conv_c64_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 1;
+        lds_set[dev].store(lds, std::memory_order_relaxed);
+    }
+    conv_c64_wide_kernel<<<grid, 512, lds, st>>>((const bf16 *)P, (unsigned)((size_t)g.M * 128 * 2), (const bf16 *)F, (bf16 *)O, g);
+    return 0;
+}
+
 // 64 -> 128 (the forward of conv2 / conv4) or 64 -> 32 (as the forward convolution the data gradient of conv1 is: dY in, flipped taps in the operand)
 bool y2_c64_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype) {
-    return dtype == YOLO2_BF16 && ksize == 3 && Cp == 64 && ldp == 64 && ((Nf == 128 && ldo == 128) || (Nf == 32 && ldo == 32));
+    if (dtype != YOLO2_BF16 || ksize != 3) return false;
+    if (Cp == 128 && ldp == 128) return Nf == 64 && ldo == 64;      // ... or 128 -> 64: the data gradients of conv2 / conv4 (conv_c64_wide_kernel)
+    return Cp == 64 && ldp == 64 && ((Nf == 128 && ldo == 128) || (Nf == 32 && ldo == 32));
 }
 
 // -> 0 launched (*rows = partial rows touched when bn_part), 1 the shape does not fit this kernel's LDS plan or its 32-filter form has no such epilogue
 // (caller takes the generic kernels)
 int y2_c64_fwd(const void *P, const void *F, void *O, int B, int H, int W, int Nf, const float *bias, float alpha, const float *bn_shift, float *bn_part,
                int cus, int *rows, hipStream_t st) {
+    if (Nf == 64) {      // 128-channel input (y2_c64_shape): plain stores only
+        if (bn_part || bias || alpha != 1.0f) return 1;
+        if (rows) *rows = 0;      // (no statistics)
+        return y2_c64_wide(P, F, O, B, H, W, cus, st);
+    }
     const long Mp = (long)B * (H + 1) * (W + 1);
     if (Mp + 2 * C64_TP >= (1L << 23) || H < 1 || W < 1 || cus < 1) return 1;
     const bool narrow = Nf == 32;

@@ -1082,11 +1082,11 @@ static int conv2d_impl(const void *P, const void *F, const float *bias, void *O,
         }
     }
     static const bool c64_direct = y2_env_int("YOLO2_C64", 1) != 0;
-    if (c64_direct && !bwd && y2_c64_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)F & 15) == 0) {      // 64 -> 128 channels (conv2 / conv4) and 64 -> 32 (conv1's data gradient): filters in registers (conv_c64.hip)
+    if (c64_direct && !bwd && y2_c64_shape(Cp, ldp, Nf, ldo, ksize, dtype) && ((uintptr_t)O & 15) == 0 && ((uintptr_t)F & 15) == 0) {      // 64 -> 128 channels (conv2 / conv4), 64 -> 32 (conv1's data gradient), 128 -> 64 (conv2 / conv4's data gradients): filters in registers (conv_c64.hip)
         const Tune tu = tune_now();
         int rows = 0;
         if (y2_c64_fwd(P, F, O, B, H, W, Nf, bias, act_alpha, bn_shift, bn_part, tu.cus, &rows, (hipStream_t)stream) == 0) {
-            const int plan_[8] = {256, Nf, 8, 8, 9, 0, rows, 1};
+            const int plan_[8] = {Nf == 64 ? 128 : 256, Nf, 8, 8, 9, 0, rows, 1};      // (positions per tile, filters)
             for (int i = 0; i < 8; ++i) g_last_plan[i] = plan_[i];
             if (bn_part) g_last_stat_rows = rows;
             Y2_CHECK_LAUNCH();
