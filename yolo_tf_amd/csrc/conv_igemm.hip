@@ -845,8 +845,10 @@ static std::atomic<int> g_pp_dmapos{y2_env_int("YOLO2_PP_SCHED", 2)};      // co
 static std::atomic<long> g_pp_min_steps{18};
 static std::atomic<long> g_pp_min_share{24};
 static const int g_pp_long_share = y2_env_int("YOLO2_PP_LONG_SHARE", 26);      // (0 = round 4's rule, for the A/B)
-// cost units charged to the owner of a stream-K tile, in K steps (conv_pp.hip "cost-balanced shares"); 0 = equal K-step shares (round 5)
-static std::atomic<int> g_pp_cv{y2_env_int("YOLO2_PP_CV", 0)};
+// cost units charged to the owner of a stream-K tile, in K steps (conv_pp.hip "cost-balanced shares"); 0 = equal K-step shares (round 5).  6 = what
+// a second prologue costs a two-segment workgroup: the dominant launches 54.46 -> 53.9 us, the step -12 us, batch 8 / multi-scale equal or better;
+// 8 and more lose again -- the owner then waits for partners that take longer (profiles/r06_pp_cv_sweep.txt, its last block)
+static std::atomic<int> g_pp_cv{y2_env_int("YOLO2_PP_CV", 6)};
 extern "C" int yolo2_debug_set_pp_cost(int cv) {
     if (cv < 0 || cv > 4096) { yolo2_set_error("yolo2_debug_set_pp_cost: 0 .. 4096 K steps"); return YOLO2_E_ARG; }
     g_pp_cv.store(cv, std::memory_order_relaxed);
