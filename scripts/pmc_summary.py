@@ -12,7 +12,7 @@ for d in sorted(glob.glob(os.path.join(root, 'p*'))):
             k = int(r['Dispatch_Id'])
             e = rows.setdefault(k, {'name': r['Kernel_Name'], 'grid': int(r['Grid_Size']) // max(int(r['Workgroup_Size']), 1)})
             e[r['Counter_Name']] = e.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
-    conv = [rows[k] for k in sorted(rows) if 'conv_igemm' in rows[k]['name'] or 'conv_wgrad' in rows[k]['name'] or 'conv3x3_tap' in rows[k]['name'] or 'conv3x3_pp' in rows[k]['name'] or 'mfma_loop' in rows[k]['name']]
+    conv = [rows[k] for k in sorted(rows) if any(t in rows[k]['name'] for t in ('conv_igemm', 'conv_wgrad', 'conv3x3_tap', 'conv3x3_pp', 'mfma_loop', 'conv_c64', 'conv_c32'))]      # (round 6: conv2's forward is conv_c64_fwd_kernel)
     for i, e in enumerate(conv):
         data.setdefault(i, {}).update(e)
 # MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (MFMA_NORM x GRBM_GUI_ACTIVE).  Round 1 divided by SQ_BUSY_CYCLES and printed > 100 %: the two
@@ -34,7 +34,7 @@ for i in [j for j in range(n) if j % 6 >= 4]:        # per layer: 3 x (igemm, wg
     wc = g('SQ_WAVE_CYCLES') or 1.0
     mf = g('SQ_INSTS_MFMA') or 1.0
     nm = e['name'].replace('void ', '')
-    nm = ('ping-pong ' + nm[nm.find('kernelI') + 7: nm.find('EEv')][:30] if 'conv3x3_pp' in nm else 'tap-fused ' if 'conv3x3_tap' in nm else 'mfma_loop ' if 'mfma_loop' in nm else 'igemm ' if 'igemm' in nm else 'wgrad ') + nm[nm.find('IDF16b') + 6: nm.find('EEv')][:40]
+    nm = ('ping-pong ' + nm[nm.find('kernelI') + 7: nm.find('EEv')][:30] if 'conv3x3_pp' in nm else 'tap-fused ' if 'conv3x3_tap' in nm else 'mfma_loop ' if 'mfma_loop' in nm else 'igemm ' if 'igemm' in nm else 'filter-in-registers conv_c64 ' if 'conv_c64' in nm else 'conv_c32 ' if 'conv_c32' in nm else 'wgrad ') + nm[nm.find('IDF16b') + 6: nm.find('EEv')][:40]
     print('| %s | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %.2f | %.2f | %.2f | %.2f | %.2f | %.1f |' % (
         nm, e['grid'], wc / 1e6, 100 * g('SQ_WAIT_ANY') / wc, 100 * g('SQ_WAIT_INST_ANY') / wc, 100 * g('SQ_ACTIVE_INST_ANY') / wc,
         100 * g('SQ_VALU_MFMA_BUSY_CYCLES') / (MFMA_NORM * (g('GRBM_GUI_ACTIVE') or 1)), 100 * g('SQ_LDS_IDX_ACTIVE') / (g('SQ_BUSY_CYCLES') or 1),
