@@ -262,7 +262,13 @@ class Engine(object):
             # (and the following layers' backward) on the main stream, so dY(L) must outlive the next layers' writes
             self.dy_ring = [staggered(max_y, T, dev) for _ in range(3)]
             self.dy_free = [None, None, None]                    # event: the side stream has finished reading that buffer
-            self.side_stream = torch.cuda.Stream(device=dev)
+            # The filter-gradient stream at HIGH priority (YOLO2_SIDE_PRIORITY=0: normal, A/B).  Both streams' big kernels need a whole CU's LDS and
+            # share the chip workgroup by workgroup; with equal priority the filter gradients fall behind the dependency chain on the main stream and
+            # pile up after its last layer, in front of Adam.  Measured in one call (profiles/r06_new_kernels.txt, last block): 3.470 -> 3.448 ms;
+            # the step on its own (non-default) stream of either priority: 3.50 .. 3.53 ms.
+            prio = int(os.environ.get('YOLO2_SIDE_PRIORITY', '-1'))
+            lo, hi = torch.cuda.Stream.priority_range()
+            self.side_stream = torch.cuda.Stream(device=dev, priority=max(min(prio, max(lo, hi)), min(lo, hi)))
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
             self.overlap_max_m = 1 << 40   # A/B: overlap only layers with at most this many output pixels
         self.img = None
