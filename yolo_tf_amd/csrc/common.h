@@ -72,9 +72,38 @@ template <int G> __device__ __forceinline__ float y2_lane_group_sum(float v) {
     if (G <= 32) v = y2_halves_sum(v);
     return v;
 }
+// ... the same for a double: every exchange moves the two 32-bit halves (the partner's VALUE is added, so both operands of the swaps are copies)
+__device__ __forceinline__ double y2_f64_from(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+template <int G> __device__ __forceinline__ double y2_lane_group_sum_f64(double v) {
+    static_assert(G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "lanes per group");
+    auto halves = [](double x, unsigned &lo, unsigned &hi) { const unsigned long long b = __builtin_bit_cast(unsigned long long, x); lo = (unsigned)b; hi = (unsigned)(b >> 32); };
+    unsigned lo, hi;
+    if (G <= 4) {
+        halves(v, lo, hi);
+        v += y2_f64_from((unsigned)__builtin_amdgcn_mov_dpp((int)lo, 0x124, 0xF, 0xF, true), (unsigned)__builtin_amdgcn_mov_dpp((int)hi, 0x124, 0xF, 0xF, true));
+    }
+    if (G <= 8) {
+        halves(v, lo, hi);
+        v += y2_f64_from((unsigned)__builtin_amdgcn_mov_dpp((int)lo, 0x128, 0xF, 0xF, true), (unsigned)__builtin_amdgcn_mov_dpp((int)hi, 0x128, 0xF, 0xF, true));
+    }
+    if (G <= 16) {      // rows 0 <-> 1, 2 <-> 3: after the swap with a copy, (a, b) = (even row's value, odd row's value) in both rows of a pair
+        halves(v, lo, hi);
+        unsigned lo2 = lo, hi2 = hi;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(lo), "+v"(lo2), "+v"(hi), "+v"(hi2));
+        v = y2_f64_from(lo, hi) + y2_f64_from(lo2, hi2);
+    }
+    if (G <= 32) {
+        halves(v, lo, hi);
+        unsigned lo2 = lo, hi2 = hi;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(lo), "+v"(lo2), "+v"(hi), "+v"(hi2));
+        v = y2_f64_from(lo, hi) + y2_f64_from(lo2, hi2);
+    }
+    return v;
+}
 #else
 __device__ inline unsigned y2_lds_addr(const void *) { return 0u; }      // (host pass of a __global__ body)
 template <int G> __device__ inline float y2_lane_group_sum(float v) { return v; }
+template <int G> __device__ inline double y2_lane_group_sum_f64(double v) { return v; }
 #endif
 
 // first-layer direct convolution (conv_first.hip), used by yolo2_conv2d / yolo2_conv2d_wgrad when the shape matches

@@ -231,16 +231,22 @@ struct RowMap {  // fixed channel group per thread, rows strided
 // lanes that share lane % tpr) and only the four waves' sums go through LDS.  The general path below leaves the whole sum to `tpr` threads, rpp serial
 // LDS reads per value: with 32 channels that is 4 threads x 1024 dependent reads, ~15 us at the end of every launch (measured: conv0's BN-backward
 // reduction took 33 us for 88 MB, its 128-channel sibling 19 us for 22 MB).
+// One 8 KB scratch for every form of the block reduction below (a __shared__ array inside a function template is allocated once per instantiation:
+// the four lane-group forms + the general path had grown the BN-backward reduction's workgroups to 48 KB of LDS)
+__device__ __forceinline__ float *colsum_scratch() {
+    __shared__ float buf[2048];
+    return buf;
+}
 template <int N, int K, int G>
 __device__ __forceinline__ void block_colsum_store_g(const float (&part)[K][N], int C, float *out, int nb) {
-    __shared__ float redw[K][4][32][N];     // [quantity][wave][channel group][value]: 8 KB
+    float *const redw = colsum_scratch();      // [quantity][wave][channel group][value]: K x 4 x 32 x N floats <= 8 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             const float v = y2_lane_group_sum<G>(part[k][j]);
-            if (lane < G) redw[k][wave][lane][j] = v;
+            if (lane < G) redw[((k * 4 + wave) * 32 + lane) * N + j] = v;
         }
     __syncthreads();
     if (threadIdx.x < G) {
@@ -249,7 +255,8 @@ __device__ __forceinline__ void block_colsum_store_g(const float (&part)[K][N], 
 #pragma unroll
             for (int j = 0; j < N; ++j)
                 out[((long)k * nb + blockIdx.x) * C + threadIdx.x * N + j] =
-                    (redw[k][0][threadIdx.x][j] + redw[k][1][threadIdx.x][j]) + (redw[k][2][threadIdx.x][j] + redw[k][3][threadIdx.x][j]);
+                    (redw[((k * 4 + 0) * 32 + threadIdx.x) * N + j] + redw[((k * 4 + 1) * 32 + threadIdx.x) * N + j]) +
+                    (redw[((k * 4 + 2) * 32 + threadIdx.x) * N + j] + redw[((k * 4 + 3) * 32 + threadIdx.x) * N + j]);
     }
 }
 template <int N, int K>
@@ -259,21 +266,22 @@ __device__ __forceinline__ void block_colsum_store(const float (&part)[K][N], co
     if (rm.tpr == 8) return block_colsum_store_g<N, K, 8>(part, C, out, nb);
     if (rm.tpr == 16) return block_colsum_store_g<N, K, 16>(part, C, out, nb);
     if (rm.tpr == 32) return block_colsum_store_g<N, K, 32>(part, C, out, nb);
-    __shared__ float red[K][256][N];  // N<=8, K<=2 -> 16 KB
+    // general path (>= 64 threads per row: at most four row slots; odd channel counts): one quantity at a time through the same scratch
+    float *const red = colsum_scratch();         // [256][N]
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int k = 0; k < K; ++k) {
+        if (k) __syncthreads();
 #pragma unroll
-        for (int j = 0; j < N; ++j) red[k][threadIdx.x][j] = rm.active ? part[k][j] : 0.f;
-    __syncthreads();
-    if (threadIdx.x < rm.tpr) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int j = 0; j < N; ++j) red[threadIdx.x * N + j] = rm.active ? part[k][j] : 0.f;
+        __syncthreads();
+        if (threadIdx.x < rm.tpr) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float s = 0.f;
-                for (int r = 0; r < rm.rpp; ++r) s += red[k][r * rm.tpr + threadIdx.x][j];
+                for (int r = 0; r < rm.rpp; ++r) s += red[(r * rm.tpr + threadIdx.x) * N + j];
                 out[((long)k * nb + blockIdx.x) * C + threadIdx.x * N + j] = s;
             }
+        }
     }
 }
 
@@ -941,14 +949,25 @@ struct SliceMap {   // 256 threads = rpb rows x lpr lanes; lane -> 16-byte chann
 };
 #define Y2_SLICE_MAX 128
 
-// sums[k][c] = sum over rows of part[k * plane + row * C + c0 + c], c < cs (f64); ends with a barrier.  A thread owns four adjacent
+// thread c < cs: sums[k] = sum over rows of part[k * plane + row * C + c0 + c] (f64); ends with a barrier.  A thread owns four adjacent
 // channels (one 16-byte load per row and plane) and every (256 / (cs / 4))-th row, so even a 128-channel slice has eight row groups
 // working in parallel: the prologue is a dependent chain in front of the whole workgroup and its length is what the fold pays.
-__device__ __forceinline__ void slice_partial_sums(const float *__restrict__ part, int rows, long plane, int C, const SliceMap &sm,
-                                                   double (*sums)[Y2_SLICE_MAX]) {
-    __shared__ double red[2][256 * 4];
+// the per-thread sums of the row groups that share a wave meet on the VALU (G = lanes per row: the lanes that share lane % G), then the four waves in LDS
+template <int G>
+__device__ __forceinline__ void slice_wave_sums(double (&v)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = y2_lane_group_sum_f64<G>(v[j]);
+}
+__device__ __forceinline__ void slice_partial_sums(const float *__restrict__ part, int rows, long plane, int C, const SliceMap &sm, double (&sums)[2]) {
+    // (round 6) 4 KB of scratch -- [wave][channel of the slice] per plane, one plane after the other -- and the results in registers of the threads that
+    // use them (thread c < cs: sums[k] of channel c0 + c) instead of 16 + 2 KB: with < 8 KB of LDS these workgroups fit on a CU beside ANY
+    // filter-gradient workgroup (140 .. 152 KB), which is where the side stream wants them
+    __shared__ double red[4 * Y2_SLICE_MAX];
     const int q = sm.cs >> 2;                               // lanes per row (cs >= 8 for bf16, >= 4 for f32: q >= 1)
     const int l4 = threadIdx.x % q, g = threadIdx.x / q, ng = 256 / q;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valu = q == 4 || q == 8 || q == 16 || q == 32;      // (q = 1, 2: tiny slices, the general path; 64 % q == 0 always)
+    sums[0] = sums[1] = 0.0;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const float *p = part + (long)k * plane + sm.c0 + l4 * 4;
@@ -970,15 +989,32 @@ __device__ __forceinline__ void slice_partial_sums(const float *__restrict__ par
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[k][g * sm.cs + l4 * 4 + j] = s[j] + t[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < sm.cs) {
+        for (int j = 0; j < 4; ++j) s[j] += t[j];
+        if (k) __syncthreads();                              // (plane 0's scratch has been read)
+        if (valu) {
+            if (q == 4) slice_wave_sums<4>(s); else if (q == 8) slice_wave_sums<8>(s); else if (q == 16) slice_wave_sums<16>(s); else slice_wave_sums<32>(s);
+            if (lane < q) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+                for (int j = 0; j < 4; ++j) red[wave * sm.cs + lane * 4 + j] = s[j];
+            }
+            __syncthreads();
+            if (threadIdx.x < sm.cs) sums[k] = (red[threadIdx.x] + red[sm.cs + threadIdx.x]) + (red[2 * sm.cs + threadIdx.x] + red[3 * sm.cs + threadIdx.x]);
+        } else {
+            // general path (slices of 4 or 8 channels: one or two lanes per row, 128 .. 256 row groups): through the same scratch in rounds of
+            // 4 * Y2_SLICE_MAX / cs row groups
+            const int gmax = 4 * Y2_SLICE_MAX / sm.cs;
             double a = 0.0;
-            for (int j = 0; j < ng; ++j) a += red[k][j * sm.cs + threadIdx.x];
-            sums[k][threadIdx.x] = a;
+            for (int g0 = 0; g0 < ng; g0 += gmax) {
+                if (g0) __syncthreads();
+                if (g >= g0 && g < g0 + gmax) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) red[(g - g0) * sm.cs + l4 * 4 + j] = s[j];
+                }
+                __syncthreads();
+                if (threadIdx.x < sm.cs)
+                    for (int j = 0; j < gmax && g0 + j < ng; ++j) a += red[j * sm.cs + threadIdx.x];
+            }
+            if (threadIdx.x < sm.cs) sums[k] = a;
         }
     }
     __syncthreads();
@@ -1000,7 +1036,7 @@ __global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__
                                                            int B, int H, int W, int C, int lda, float eps, float alpha, float *__restrict__ zero, long zero_vec4) {
     constexpr int N = Vec16<T>::N;
     const SliceMap sm(C, N);
-    __shared__ double sums[2][Y2_SLICE_MAX];
+    double sums[2];
     __shared__ float cst[3][Y2_SLICE_MAX];
     // the first pixel row's data is requested BEFORE the prologue: its HBM latency runs under the partial-row reduction
     const PoolRow pr(H, W, C);
@@ -1020,8 +1056,8 @@ __global__ __launch_bounds__(256) void bn_leaky_fin_kernel(const T *__restrict__
     slice_partial_sums(part, rows, (long)Y2_BN_PART_ROWS * C, C, sm, sums);
     if (threadIdx.x < sm.cs) {
         const int c = sm.c0 + threadIdx.x;
-        const double dm = sums[0][threadIdx.x] / (double)Mstat;
-        const double var = sums[1][threadIdx.x] / (double)Mstat - dm * dm;
+        const double dm = sums[0] / (double)Mstat;
+        const double var = sums[1] / (double)Mstat - dm * dm;
         const float fm = (float)((double)shift[c] + dm), fv = (float)(var > 0.0 ? var : 0.0);
         cst[0][threadIdx.x] = fm;
         cst[1][threadIdx.x] = (1.0f / sqrtf(fv + eps)) * gamma[c];
@@ -1108,7 +1144,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T *__restri
                                                                float eps, float alpha, float *__restrict__ zero, long zero_vec4) {
     constexpr int N = Vec16<T>::N;
     const SliceMap sm(C, N);
-    __shared__ double sums[2][Y2_SLICE_MAX];
+    double sums[2];
     __shared__ float cst[2][Y2_SLICE_MAX];
     const PoolRow pr(H, W, C);
     const long ML = POOL ? (long)B * pr.OH * pr.OW : (long)B * H * W;
@@ -1129,7 +1165,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fin_kernel(const T *__restri
     if (r < ML) fetch(r, v, d, pack);        // in flight under the prologue
     slice_partial_sums(part, rows, plane, C, sm, sums);
     if (threadIdx.x < sm.cs) {
-        const float dg = (float)sums[0][threadIdx.x], db = (float)sums[1][threadIdx.x];
+        const float dg = (float)sums[0], db = (float)sums[1];
         cst[0][threadIdx.x] = dg;
         cst[1][threadIdx.x] = db;
         if (blockIdx.x == 0) {
