@@ -110,7 +110,7 @@ class _PartPool(object):
 
 
 class Engine(object):
-    def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None, sync_bn=False):
+    def __init__(self, graph, batch_size, dtype='bf16', training=True, seed=0, device=None, sync_bn=False, side_priority=-1):
         if not torch.cuda.is_available():
             raise RuntimeError('yolo_tf_amd.Engine needs an MI355X (no CPU path exists)')
         ops._lib.load()
@@ -266,7 +266,8 @@ class Engine(object):
             # share the chip workgroup by workgroup; with equal priority the filter gradients fall behind the dependency chain on the main stream and
             # pile up after its last layer, in front of Adam.  Measured in one call (profiles/r06_new_kernels.txt, last block): 3.470 -> 3.448 ms;
             # the step on its own (non-default) stream of either priority: 3.50 .. 3.53 ms.
-            prio = int(os.environ.get('YOLO2_SIDE_PRIORITY', '-1'))
+            # (side_priority: data-parallel sessions pass 0 -- the collective's stream is the one high-priority stream there, as measured in rounds 3-5)
+            prio = int(os.environ.get('YOLO2_SIDE_PRIORITY', str(side_priority)))
             lo, hi = torch.cuda.Stream.priority_range()
             self.side_stream = torch.cuda.Stream(device=dev, priority=max(min(prio, max(lo, hi)), min(lo, hi)))
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)

@@ -41,7 +41,8 @@ class TrainSession(object):
                 traced[wh] = builder.trace(wh[0], wh[1], training=True)
         largest = max(traced, key=lambda wh: wh[0] * wh[1])
         assert all(w <= largest[0] and h <= largest[1] for w, h in traced), 'one size must contain all the others'
-        self.engine = Engine(traced[largest][0], batch_size, dtype, training=True, seed=seed, sync_bn=sync_bn and world_size > 1)
+        self.engine = Engine(traced[largest][0], batch_size, dtype, training=True, seed=seed, sync_bn=sync_bn and world_size > 1,
+                             side_priority=-1 if world_size == 1 else 0)
         e = self.engine
         if e.sync_bn:                # batch moments and BN-backward sums over all replicas ([mi355x] sync_bn; default: replica-local like N reference processes)
             import torch.distributed as dist
