@@ -119,9 +119,11 @@ int yolo2_filter_prep(const float *W, void *Ffwd, void *Fdgr, int ksize, int Cin
 
 /* The same for every layer of a network in one launch.  `descs_device` is a DEVICE array of n descriptors
  * sorted by first_block; layer i owns blocks [first_block_i, first_block_{i+1}) and needs
- * ksize^2 * ceil(ldcin/T) * ceil(ldcout/T) of them, T = YOLO2_FILTER_PREP_TILE; total_blocks = end of the last layer.
- * ldcin, ldcout must be multiples of 8 and Ffwd/Fdgr 16-byte aligned. */
-#define YOLO2_FILTER_PREP_TILE 64
+ * yolo2_filter_prep_blocks(ksize, ldcin, ldcout) = ksize^2 * ceil(ldcin / YOLO2_FILTER_PREP_TILE) * ceil(ldcout / YOLO2_FILTER_PREP_TILE_N) of them
+ * (one block = one (c, n) tile of one tap); total_blocks = end of the last layer.  ldcin, ldcout must be multiples of 8 and Ffwd/Fdgr 16-byte aligned. */
+#define YOLO2_FILTER_PREP_TILE 64       /* input channels per tile */
+#define YOLO2_FILTER_PREP_TILE_N 128   /* filters per tile (round 6: 128 -- the master arrays then move in 512-byte runs) */
+int yolo2_filter_prep_blocks(int ksize, int ldcin, int ldcout);
 typedef struct yolo2_filter_desc {
     const float *W;      /* HWIO f32 master weights */
     void *Ffwd;          /* [Cout][k*k*ldcin]  or NULL */

@@ -807,7 +807,7 @@ def test_filter_prep_batch_matches_per_layer(ops):
             ops.filter_prep(w, ef, ed, k, cin, ldcin, cout, ldcout, tdtype)
             d.W, d.Ffwd, d.Fdgr = w.data_ptr(), ff.data_ptr(), fd.data_ptr()
             d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, cin, ldcin, cout, ldcout, first
-            first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+            first += ops.filter_prep_blocks(k, ldcin, ldcout)
             keep.append((w, ff, fd, ef, ed))
         descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
         ops.filter_prep_batch(descs, len(layers), first, tdtype)
@@ -844,7 +844,7 @@ def test_adam_fused_with_filter_prep_is_bit_identical(ops):
                 fd = torch.full((cin * k * k * ldcout,), 3.0, dtype=tdtype, device='cuda')
                 d.W, d.Ffwd, d.Fdgr = P[o:].data_ptr(), ff.data_ptr(), fd.data_ptr()
                 d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, cin, ldcin, cout, ldcout, first
-                first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+                first += ops.filter_prep_blocks(k, ldcin, ldcout)
                 keep.append((ff, fd))
                 small += [o2, n2]
             descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()

@@ -108,6 +108,7 @@ QUERIES = {
     'yolo2_shutdown': (_i, []),
     'yolo2_crc32c': (ctypes.c_uint32, [_p, ctypes.c_size_t, ctypes.c_uint32]),
     'yolo2_conv2d_wgrad_accumulates': (_i, [_i] * 9),            # 0 / 1, not a status
+    'yolo2_filter_prep_blocks': (_i, [_i, _i, _i]),               # a count, not a status
     'yolo2_conv2d_dgrad_bn_fuses': (_i, [_i] * 6),               # 0 / 1, not a status
     'yolo2_debug_set_wgrad_variant': (None, [_i]),
     'yolo2_last_bn_part_rows': (_i, []),

@@ -130,28 +130,68 @@ __device__ __forceinline__ void store8(T *dst, const float (&v)[8]) {
         reinterpret_cast<f32x4 *>(dst)[1] = b;
     }
 }
+// Both operand layouts of one TC x TN (c, n) tile of one tap, from its fresh f32 values in LDS: Ffwd rows n with c contiguous (the transpose),
+// Fdgr rows c with n contiguous and the taps flipped.  8 elements (16 bytes of bf16) per lane and store.
+template <typename T>
+__device__ __forceinline__ void filter_tile_emit(const yolo2_filter_desc &d, const float (&tile)[YOLO2_FILTER_PREP_TILE][YOLO2_FILTER_PREP_TILE_N + 1], int tap, int taps,
+                                                 int c0, int n0, int tid) {
+    constexpr int TC = YOLO2_FILTER_PREP_TILE, TN = YOLO2_FILTER_PREP_TILE_N;
+    T *Ff = (T *)d.Ffwd, *Fd = (T *)d.Fdgr;
+    if (Ff) {       // rows n, c contiguous: TC / 8 lanes per row (the tile's odd pitch keeps the transposed reads conflict-free)
+        constexpr int LPR = TC / 8, RPP = 256 / LPR;
+        const int g8 = (tid % LPR) * 8, rr = tid / LPR;
+        const long Kf = (long)taps * d.ldcin;
+#pragma unroll
+        for (int p = 0; p < TN / RPP; ++p) {
+            const int nl = rr + p * RPP, nn = n0 + nl, c = c0 + g8;
+            if (nn < d.cout && c < d.ldcin) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[g8 + j][nl];
+                store8<T>(Ff + nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps), v);
+            }
+        }
+    }
+    if (Fd) {       // rows c, n contiguous, taps flipped: TN / 8 lanes per row
+        constexpr int LPR = TN / 8, RPP = 256 / LPR;
+        const int g8 = (tid % LPR) * 8, rr = tid / LPR;
+        const long Kd = (long)taps * d.ldcout;
+        const int tp = taps - 1 - tap;
+#pragma unroll
+        for (int p = 0; p < TC / RPP; ++p) {
+            const int cl = rr + p * RPP, c = c0 + cl, nn = n0 + g8;
+            if (c < d.cin && nn < d.ldcout) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tile[cl][g8 + j];
+                store8<T>(Fd + c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps), v);
+            }
+        }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void filter_prep_batch_kernel(const yolo2_filter_desc *__restrict__ descs, int n) {
-    constexpr int TS = YOLO2_FILTER_PREP_TILE;
-    __shared__ float tile[TS][TS + 1];
+    constexpr int TC = YOLO2_FILTER_PREP_TILE, TN = YOLO2_FILTER_PREP_TILE_N;
+    __shared__ float tile[TC][TN + 1];
     int li = 0;
     while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].first_block) ++li;
     const yolo2_filter_desc d = descs[li];
     const int taps = d.ksize * d.ksize;
-    const int ctiles = (d.ldcin + TS - 1) / TS, ntiles = (d.ldcout + TS - 1) / TS;
+    const int ctiles = (d.ldcin + TC - 1) / TC, ntiles = (d.ldcout + TN - 1) / TN;
     int u = blockIdx.x - d.first_block;
     const int ntile = u % ntiles; u /= ntiles;
     const int ctile = u % ctiles;
     const int tap = u / ctiles;
-    const int n0 = ntile * TS, c0 = ctile * TS;
+    const int n0 = ntile * TN, c0 = ctile * TC;
     const int tid = threadIdx.x;
     const float *Wt = d.W + (long)tap * d.cin * d.cout;
     const bool vec_ok = (d.cout & 3) == 0 && (((uintptr_t)d.W) & 15) == 0;
-    {   // load: 16 lanes x float4 per row, 16 rows per pass
-        const int col = (tid & 15) * 4, r0 = tid >> 4;
+    {   // load: TN / 4 lanes x float4 per row
+        constexpr int LPR = TN / 4, RPP = 256 / LPR;
+        const int col = (tid % LPR) * 4, r0 = tid / LPR;
 #pragma unroll
-        for (int p = 0; p < TS / 16; ++p) {
-            const int c = c0 + r0 + p * 16, nn = n0 + col;
+        for (int p = 0; p < TC / RPP; ++p) {
+            const int c = c0 + r0 + p * RPP, nn = n0 + col;
             float v[4] = {0.f, 0.f, 0.f, 0.f};
             if (c < d.cin) {
                 if (vec_ok && nn + 3 < d.cout) {
@@ -164,41 +204,17 @@ __global__ __launch_bounds__(256) void filter_prep_batch_kernel(const yolo2_filt
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[r0 + p * 16][col + j] = v[j];
+            for (int j = 0; j < 4; ++j) tile[r0 + p * RPP][col + j] = v[j];
         }
     }
     __syncthreads();
-    T *Ff = (T *)d.Ffwd, *Fd = (T *)d.Fdgr;
-    const int g8 = (tid & 7) * 8, rr = tid >> 3;       // 8 lanes x 8 elements per row, 32 rows per pass
-    if (Ff) {       // rows n, c contiguous: transpose through LDS ((c + n) % 64 distinct per pass: conflict-free)
-        const long Kf = (long)taps * d.ldcin;
-#pragma unroll
-        for (int p = 0; p < TS / 32; ++p) {
-            const int nl = rr + p * 32, nn = n0 + nl, c = c0 + g8;
-            if (nn < d.cout && c < d.ldcin) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tile[g8 + j][nl];
-                store8<T>(Ff + nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps), v);
-            }
-        }
-    }
-    if (Fd) {       // rows c, n contiguous, taps flipped
-        const long Kd = (long)taps * d.ldcout;
-        const int tp = taps - 1 - tap;
-#pragma unroll
-        for (int p = 0; p < TS / 32; ++p) {
-            const int cl = rr + p * 32, c = c0 + cl, nn = n0 + g8;
-            if (c < d.cin && nn < d.ldcout) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tile[cl][g8 + j];
-                store8<T>(Fd + c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps), v);
-            }
-        }
-    }
+    filter_tile_emit<T>(d, tile, tap, taps, c0, n0, tid);
 }
 
+extern "C" int yolo2_filter_prep_blocks(int ksize, int ldcin, int ldcout) {
+    if (ksize < 1 || ldcin < 1 || ldcout < 1) return 0;
+    return ksize * ksize * cdiv(ldcin, YOLO2_FILTER_PREP_TILE) * cdiv(ldcout, YOLO2_FILTER_PREP_TILE_N);
+}
 extern "C" int yolo2_filter_prep_batch(const yolo2_filter_desc *descs_device, int n, int total_blocks, int dtype, void *stream) {
     Y2_CHECK_ARG(descs_device && n > 0 && total_blocks > 0);
     Y2_DISPATCH_DTYPE(dtype, filter_prep_batch_kernel<T><<<total_blocks, 256, 0, (hipStream_t)stream>>>(descs_device, n));
@@ -2139,26 +2155,29 @@ __global__ __launch_bounds__(256) void adam_filter_prep_kernel(const yolo2_filte
         }
         return;
     }
-    constexpr int TS = YOLO2_FILTER_PREP_TILE;
-    __shared__ float tile[TS][TS + 1];
+    constexpr int TC = YOLO2_FILTER_PREP_TILE, TN = YOLO2_FILTER_PREP_TILE_N;
+    __shared__ float tile[TC][TN + 1];
     int li = 0;
     while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].first_block) ++li;
     const yolo2_filter_desc d = descs[li];
     const int taps = d.ksize * d.ksize;
-    const int ctiles = (d.ldcin + TS - 1) / TS, ntiles = (d.ldcout + TS - 1) / TS;
+    const int ctiles = (d.ldcin + TC - 1) / TC, ntiles = (d.ldcout + TN - 1) / TN;
     int u = blockIdx.x - d.first_block;
     const int ntile = u % ntiles; u /= ntiles;
     const int ctile = u % ctiles;
     const int tap = u / ctiles;
-    const int n0 = ntile * TS, c0 = ctile * TS;
+    const int n0 = ntile * TN, c0 = ctile * TC;
     const int tid = threadIdx.x;
     const long base = (d.W - a.params) + (long)tap * d.cin * d.cout;       // element offset of this tap's [cin][cout] plane in the arenas
     const bool vec_ok = (d.cout & 3) == 0 && ((base & 3) == 0);
     {
-        const int col = (tid & 15) * 4, r0 = tid >> 4;
+        // TN / 4 lanes x float4 per row: a 128-wide tile reads and writes w / m / v / g in 512-byte runs (round 6: with 64 x 64 tiles the four streams
+        // moved in 256-byte runs at 5.5-5.7 TB/s where the linear adam_kernel reaches 6.9)
+        constexpr int LPR = TN / 4, RPP = 256 / LPR;
+        const int col = (tid % LPR) * 4, r0 = tid / LPR;
 #pragma unroll
-        for (int p = 0; p < TS / 16; ++p) {
-            const int c = c0 + r0 + p * 16, nn = n0 + col;
+        for (int p = 0; p < TC / RPP; ++p) {
+            const int c = c0 + r0 + p * RPP, nn = n0 + col;
             float w4[4] = {0.f, 0.f, 0.f, 0.f};
             if (c < d.cin) {
                 const long o = base + (long)c * d.cout + nn;
@@ -2184,39 +2203,11 @@ __global__ __launch_bounds__(256) void adam_filter_prep_kernel(const yolo2_filte
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) tile[r0 + p * 16][col + j] = w4[j];
+            for (int j = 0; j < 4; ++j) tile[r0 + p * RPP][col + j] = w4[j];
         }
     }
     __syncthreads();
-    T *Ff = (T *)d.Ffwd, *Fd = (T *)d.Fdgr;
-    const int g8 = (tid & 7) * 8, rr = tid >> 3;
-    if (Ff) {
-        const long Kf = (long)taps * d.ldcin;
-#pragma unroll
-        for (int p = 0; p < TS / 32; ++p) {
-            const int nl = rr + p * 32, nn = n0 + nl, c = c0 + g8;
-            if (nn < d.cout && c < d.ldcin) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tile[g8 + j][nl];
-                store8<T>(Ff + nn * Kf + y2_filter_koff(tap, c, d.ldcin, taps), v);
-            }
-        }
-    }
-    if (Fd) {
-        const long Kd = (long)taps * d.ldcout;
-        const int tp = taps - 1 - tap;
-#pragma unroll
-        for (int p = 0; p < TS / 32; ++p) {
-            const int cl = rr + p * 32, c = c0 + cl, nn = n0 + g8;
-            if (c < d.cin && nn < d.ldcout) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = tile[cl][g8 + j];
-                store8<T>(Fd + c * Kd + y2_filter_koff(tp, nn, d.ldcout, taps), v);
-            }
-        }
-    }
+    filter_tile_emit<T>(d, tile, tap, taps, c0, n0, tid);
 }
 extern "C" int yolo2_adam_filter_prep(const yolo2_filter_desc *descs_device, int n, int total_blocks, const long *small_ranges_device, int n_small,
                                       float *params, const float *grads, float *m, float *v, float alpha, float beta1, float beta2, float eps,

@@ -114,6 +114,7 @@ class Engine(object):
         if not torch.cuda.is_available():
             raise RuntimeError('yolo_tf_amd.Engine needs an MI355X (no CPU path exists)')
         ops._lib.load()
+        self.side_priority = side_priority
         # Synchronised batch normalisation (data-parallel option, [mi355x] sync_bn): batch moments and the BN-backward sums are summed over
         # the replicas, so N ranks x B images train like one process with N x B images.  The reference is single-device (local statistics
         # are what N independent replicas of it would compute; that stays the default).  Costs two small collectives per BN layer and
@@ -267,7 +268,7 @@ class Engine(object):
             # pile up after its last layer, in front of Adam.  Measured in one call (profiles/r06_new_kernels.txt, last block): 3.470 -> 3.448 ms;
             # the step on its own (non-default) stream of either priority: 3.50 .. 3.53 ms.
             # (side_priority: data-parallel sessions pass 0 -- the collective's stream is the one high-priority stream there, as measured in rounds 3-5)
-            prio = int(os.environ.get('YOLO2_SIDE_PRIORITY', str(side_priority)))
+            prio = int(os.environ.get('YOLO2_SIDE_PRIORITY', str(self.side_priority)))
             lo, hi = torch.cuda.Stream.priority_range()
             self.side_stream = torch.cuda.Stream(device=dev, priority=max(min(prio, max(lo, hi)), min(lo, hi)))
             self.overlap_wgrad = os.environ.get('YOLO2_OVERLAP_WGRAD', '1') != '0'   # 0: single stream (clean per-kernel profiles)
@@ -434,7 +435,7 @@ class Engine(object):
             d.Ffwd = st['Ffwd'].data_ptr()
             d.Fdgr = st['Fdgr'].data_ptr() if 'Fdgr' in st else None
             d.ksize, d.cin, d.ldcin, d.cout, d.ldcout, d.first_block = k, op['cin'], ldcin, op['cout'], ldcout, first
-            first += k * k * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+            first += ops.filter_prep_blocks(k, ldcin, ldcout)
         raw = bytes(arr)
         self._fdesc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self._fdesc_n, self._fdesc_blocks = len(convs), first

@@ -62,6 +62,14 @@ def conv2d_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype):
     return bool(lib.yolo2_conv2d_dgrad_bn_fuses(B, H, W, Nf, ksize, dtype_code(dtype)))
 
 
+def filter_prep_blocks(ksize, ldcin, ldcout):
+    """Workgroups one layer takes in ``filter_prep_batch`` / ``adam_filter_prep`` (the layer's ``first_block`` arithmetic)."""
+    lib = _lib.load()
+    if 'yolo2_filter_prep_blocks' in _lib.MISSING:       # (an earlier round's library, YOLO2_LIB_BASELINE=1: 64 x 64 tiles)
+        return ksize * ksize * ((ldcin + 63) // 64) * ((ldcout + 63) // 64)
+    return int(lib.yolo2_filter_prep_blocks(ksize, ldcin, ldcout))
+
+
 def bn_part_to_grads(bn_part, C, dgamma, dbeta):
     call('yolo2_bn_part_to_grads', ptr(bn_part), C, ptr(dgamma), ptr(dbeta), _stream())
 
