@@ -651,7 +651,7 @@ BORDERS = ['first_row', 'last_row', 'first_col', 'last_col', 'corners', 'frame']
 
 @pytest.mark.parametrize('which', BORDERS)
 @pytest.mark.parametrize('mode', ['bf16', 'bf16_row2', 'bf16_row4', 'bf16_row5', 'bf16_pertap'])
-@pytest.mark.parametrize('shape', [(2, 13, 13, 128, 128), (2, 16, 15, 64, 64), (1, 26, 27, 64, 128), (3, 7, 52, 128, 64)])
+@pytest.mark.parametrize('shape', [(2, 13, 13, 128, 128), (2, 16, 15, 64, 64), (1, 26, 27, 64, 128), (3, 7, 52, 128, 64), (3, 4, 32, 32, 64)])
 def test_conv_wgrad_border_only_inputs(ops, shape, mode, which):
     """Padded-index kernels fail at image borders first (conv_wgrad3.hip: the left neighbour of column 0 is the previous row's zero column,
     rows outside the image read as zeros through the buffer range check).  Inputs that are non-zero ONLY on the border -- in x, then in dy --
@@ -678,6 +678,32 @@ def test_conv_wgrad_border_only_inputs(ops, shape, mode, which):
         if mode.startswith('bf16_row'):
             assert plan['pair'] == 3, plan
         assert_wgrad_exact_products(host(dW).reshape(3, 3, Cin, Cout), ref, 'wgrad border-only %s in %s %s %s' % (which, side, shape, mode))
+
+
+C32W_SHAPES = [(2, 16, 16), (3, 5, 32), (1, 9, 208), (2, 31, 48), (1, 1, 16), (1, 2, 16), (1, 3, 304), (5, 4, 224), (2, 2, 240), (7, 3, 64)]
+
+
+@pytest.mark.parametrize('shape', C32W_SHAPES, ids=['x'.join(map(str, c)) for c in C32W_SHAPES])
+def test_conv1_wgrad_all_taps_per_workgroup(ops, shape):
+    """conv_wgrad_c32.hip: the filter gradient of a 32 -> 64 channel 3x3 layer (Darknet-19 conv1; reference model/yolo2/inference.py:76, gradient by
+    train.py:127-129) with all nine taps in one workgroup over a run of image rows: X rows R - 1 / R / R + 1 from a ring of image rows, a kernel row
+    that leaves the image sits the step out.  Shapes: rows that end images inside a workgroup's run (B > 1 with few rows), one-row images (both
+    vertical neighbours outside), one workgroup (plain stores into a dirty buffer), 224 / 240 / 304-wide rows (the deepest / the shallower ring).
+    Per element against the f64 sum of the exact bf16 products."""
+    B, H, W = shape
+    Cin, Cout, T = 32, 64, torch.bfloat16
+    rng = np.random.RandomState(sum(shape) + 5)
+    x = bf16_round(rng.randn(B, H, W, Cin).astype(np.float32))
+    dy = bf16_round(rng.randn(B, H, W, Cout).astype(np.float32))
+    ref = R.conv2d_wgrad(x.astype(np.float64), dy.astype(np.float64), 3, 3)
+    accumulates = ops.conv2d_wgrad_accumulates(B, H, W, Cin, Cin, Cout, Cout, 3, T)
+    dW = torch.zeros(9 * Cin * Cout, dtype=torch.float32, device='cuda') if accumulates else torch.full((9 * Cin * Cout,), 7.0, dtype=torch.float32, device='cuda')
+    ops.conv2d_wgrad(dev(x, T), dev(dy, T), dW, B, H, W, Cin, Cin, Cout, Cout, 3)
+    torch.cuda.synchronize()
+    plan = ops.last_wgrad_plan()
+    assert (plan['BC'], plan['BN'], plan['waves'], plan['pair']) == (32, 64, 12, 9), plan
+    assert bool(plan['direct']) == (not accumulates) and (plan['blocks'] == 1) == (not accumulates), (plan, accumulates)
+    assert_wgrad_exact_products(host(dW).reshape(3, 3, Cin, Cout), ref, 'conv1 wgrad, nine taps per workgroup %s' % (shape,))
 
 
 @pytest.mark.parametrize('chan', [(32, 64, 256), (64, 128, 128)], ids=['conv1', 'conv2_4'])      # (Cin, Cout of the LAYER, plan BM of its data gradient)

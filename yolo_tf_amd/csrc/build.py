@@ -14,6 +14,7 @@ SOURCES = {
     'conv_s4.hip': [],
     'conv_wgrad.hip': [],
     'conv_wgrad3.hip': [],
+    'conv_wgrad_c32.hip': [],
     'conv_c32.hip': [],
     'conv_c64.hip': [],
     'conv_d1.hip': [],

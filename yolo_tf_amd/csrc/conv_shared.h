@@ -66,6 +66,12 @@ Y2W3Plan y2_wgrad3_plan(int B, int H, int W, int Cin, int Cout, int cus, int for
 int y2_wgrad3_launch(const Y2W3Plan &p, const void *X, const void *dY, float *dW, int B, int H, int W, int Cin, int ldx, int Cout, int ldy, hipStream_t st);
 void y2_magic_u32(unsigned d, unsigned *m, unsigned *s);
 
+// conv_wgrad_c32.hip: 3x3 filter gradient for 32 input channels and 64 filters (Darknet-19 conv1), bf16: all nine taps in one workgroup over a run of image
+// rows, every operand byte read once.  y2_w32_wgrad returns non-zero when the rows do not fit its LDS plan (the caller then takes the per-tap kernel).
+bool y2_w32_shape(int Cin, int ldx, int Cout, int ldy, int ksize, int dtype);
+int y2_w32_blocks(int B, int H, int W, int cus);      // workgroups of the launch; 0: not taken
+int y2_w32_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, int cus, int *blocks, hipStream_t st);
+
 // conv_c32.hip: persistent 3x3 forward for 32-channel inputs and 64 filters (Darknet-19 conv1), bf16.  y2_c32_fwd returns non-zero when the image is
 // too wide for its LDS plan (the caller then takes the generic kernels).
 bool y2_c32_shape(int Cp, int ldp, int Nf, int ldo, int ksize, int dtype);

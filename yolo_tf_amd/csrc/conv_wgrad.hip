@@ -511,6 +511,10 @@ extern "C" int yolo2_conv2d_wgrad_accumulates(int B, int H, int W, int Cin, int 
     static const bool first_direct = y2_env_int("YOLO2_FIRST_DIRECT", 1) != 0;
     if (first_direct && Cin <= 8 && y2_first_layer_shape(8, ldx, Cout, ldy, ksize)) return 1;      // cross-workgroup atomics
     if (g_wgrad_variant != 0) return 1;
+    if (g_wgrad_variant_raw.load(std::memory_order_relaxed) == 0 && y2_w32_shape(Cin, ldx, Cout, ldy, ksize, dtype)) {
+        const int blocks = y2_w32_blocks(B, H, W, wgrad_cus());
+        if (blocks > 0) return blocks == 1 ? 0 : 1;                  // one workgroup stores, several add
+    }
     {
         const Y2W3Plan rp = wgrad_row_plan(B, H, W, Cin, Cout, ksize, dtype);
         if (rp.variant >= 0) return rp.direct ? 0 : 1;
@@ -539,6 +543,15 @@ extern "C" int yolo2_conv2d_wgrad(const void *X, const void *dY, float *dW, int 
         for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = -1;
         Y2_CHECK_LAUNCH();
         return YOLO2_OK;
+    }
+    if (g_wgrad_variant_raw.load(std::memory_order_relaxed) == 0 && y2_w32_shape(Cin, ldx, Cout, ldy, ksize, dtype)) {
+        int blocks = 0;                                                                 // conv1: all nine taps per workgroup (conv_wgrad_c32.hip)
+        if (y2_w32_wgrad(X, dY, dW, B, H, W, wgrad_cus(), &blocks, st) == 0) {
+            const int plan[8] = {32, 64, 12, 9, blocks, 0, blocks, blocks == 1};
+            for (int i = 0; i < 8; ++i) g_last_wgrad_plan[i] = plan[i];
+            Y2_CHECK_LAUNCH();
+            return YOLO2_OK;
+        }
     }
     {
         const Y2W3Plan rp = wgrad_row_plan(B, H, W, Cin, Cout, ksize, dtype);
