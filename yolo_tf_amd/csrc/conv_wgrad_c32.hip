@@ -20,6 +20,7 @@
 #include "common.h"
 #include "conv_shared.h"
 #include <atomic>
+#include <type_traits>
 
 struct W32Geo {
     int H, W, BH;          // image rows / columns, image rows of the batch
@@ -233,19 +234,23 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
         return;
     }
     // ---- output: dW is HWIO [tap][32][64]; accumulator register r of lane l is channel 4 (l >> 5) + (r & 3) + 8 (r >> 2), filter 32 j + (l & 31)
-    const bool direct = gridDim.x == 1;
+    auto write_out = [&](auto direct_) {
+        constexpr bool DIRECT = decltype(direct_)::value;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float *out = dW + (kr * 3 + d) * (32 * 64) + (4 * (lane >> 5)) * 64 + (lane & 31);
+        for (int d = 0; d < 3; ++d) {
+            float *out = dW + (kr * 3 + d) * (32 * 64) + (4 * (lane >> 5)) * 64 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float *p = out + ((r & 3) + 8 * (r >> 2)) * 64 + 32 * j;
-                if (direct) *p = acc[d][j][r];
-                else unsafeAtomicAdd(p, acc[d][j][r]);
-            }
-    }
+                for (int r = 0; r < 16; ++r) {
+                    float *p = out + ((r & 3) + 8 * (r >> 2)) * 64 + 32 * j;
+                    if (DIRECT) *p = acc[d][j][r];
+                    else unsafeAtomicAdd(p, acc[d][j][r]);
+                }
+        }
+    };
+    if (gridDim.x == 1) write_out(std::true_type{});       // one workgroup: it owns dW (which may be dirty)
+    else write_out(std::false_type{});
 }
 
 static const bool g_w32_on = y2_env_int("YOLO2_WGRAD_C32", 1) != 0;
