@@ -33,7 +33,8 @@ struct W32Geo {
 };
 
 // D: image rows in flight ahead of the one being multiplied (2 where LDS allows: W <= 224).  ABL (timing ablations of -DY2W32_EXPERIMENTS builds, results
-// wrong by design): 1 = no MFMA, 2 = no fragment reads, 4 = no DMA inside the loop, 32 = no output, 64 = no pixel-group reduction, 256 = the workgroup returns at once
+// wrong by design): 1 = no MFMA, 2 = no fragment reads, 4 = no DMA inside the loop, 32 = no output, 64 = no pixel-group reduction, 256 = the workgroup returns at once,
+// 512 = wall-clock (100 MHz) stamps: every wave leaves {kernel, prologue, row loop, drain + first barrier, LDS reduction, atomics issued + acknowledged} cycles behind dW (the caller allocates 18432 + blocks x 12 x 16 floats)
 template <int D, int ABL = 0>
 __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restrict__ X, unsigned x_bytes, const bf16 *__restrict__ dY, unsigned y_bytes,
                                                              float *__restrict__ dW, W32Geo g) {
@@ -46,6 +47,8 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
     const int R0 = (int)blockIdx.x * g.rpw, R1 = min(R0 + g.rpw, g.BH);      // this workgroup's image rows (counted over the batch)
     if (R0 >= g.BH) return;
     const int nsteps = R1 - R0;
+    unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tm3 = 0, tm4 = 0;
+    if constexpr (ABL & 512) tm0 = wall_clock64();
     if constexpr (ABL & 256) { if (dW[0] == 123.456f) dW[1] = (float)nsteps; return; }
 
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16 *>(X), 0, x_bytes, 0x00020000);
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
+    if constexpr (ABL & 512) tm1 = wall_clock64();
     for (int s = 0; s < nsteps; ++s) {
         wait_stage();
         __builtin_amdgcn_s_barrier();                       // stage s is in LDS for every wave; every wave has left step s - 1 (its slots are refilled below)
@@ -193,8 +197,10 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
     }
     // ---- the four pixel groups hold partial sums over disjoint pixels: groups 2, 3 -> 0, 1, then 1 -> 0, through LDS (every DMA has landed -- the
     // padding instructions too, they write zeros -- and been read)
+    if constexpr (ABL & 512) { __builtin_amdgcn_sched_barrier(0); tm2 = wall_clock64(); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (ABL & 512) { __builtin_amdgcn_sched_barrier(0); tm3 = wall_clock64(); }
     f32x4 *img = reinterpret_cast<f32x4 *>(smem);
 #pragma unroll
     for (int h = (ABL & 64) ? 0 : 2; h >= 1; h >>= 1) {
@@ -228,6 +234,17 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
         }
         if (h > 1) __syncthreads();
     }
+    if constexpr (ABL & 512) {
+        __builtin_amdgcn_sched_barrier(0);
+        tm4 = wall_clock64();
+        if (pg != 0) {
+            if (lane == 0) {
+                unsigned long long *dbg = reinterpret_cast<unsigned long long *>(dW + 18432) + ((long)blockIdx.x * 12 + wave) * 8;
+                dbg[0] = tm4 - tm0; dbg[1] = tm1 - tm0; dbg[2] = tm2 - tm1; dbg[3] = tm3 - tm2; dbg[4] = tm4 - tm3; dbg[5] = 0; dbg[6] = (unsigned long long)nsteps; dbg[7] = 0;
+            }
+            return;
+        }
+    }
     if (pg != 0) return;
     if constexpr (ABL & 32) {
         if (acc[0][0][0] == 123.456f && acc[2][1][5] == 1.0f) dW[0] = acc[1][1][3];
@@ -251,6 +268,16 @@ __global__ __launch_bounds__(768) void conv_wgrad_c32_kernel(const bf16 *__restr
     };
     if (gridDim.x == 1) write_out(std::true_type{});       // one workgroup: it owns dW (which may be dirty)
     else write_out(std::false_type{});
+    if constexpr (ABL & 512) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tm5 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tm6 = wall_clock64();
+        if (lane == 0) {
+            unsigned long long *dbg = reinterpret_cast<unsigned long long *>(dW + 18432) + ((long)blockIdx.x * 12 + wave) * 8;
+            dbg[0] = tm6 - tm0; dbg[1] = tm1 - tm0; dbg[2] = tm2 - tm1; dbg[3] = tm3 - tm2; dbg[4] = tm4 - tm3; dbg[5] = tm5 - tm4; dbg[6] = (unsigned long long)nsteps; dbg[7] = tm6 - tm5;
+        }
+    }
 }
 
 static const bool g_w32_on = y2_env_int("YOLO2_WGRAD_C32", 1) != 0;
@@ -318,7 +345,7 @@ int y2_w32_wgrad(const void *X, const void *dY, float *dW, int B, int H, int W, 
         return 0;                                                                                                                             \
     }
         if (D == 2) {
-            W32_LAUNCH_ABL(1) W32_LAUNCH_ABL(2) W32_LAUNCH_ABL(3) W32_LAUNCH_ABL(4) W32_LAUNCH_ABL(7) W32_LAUNCH_ABL(32) W32_LAUNCH_ABL(96) W32_LAUNCH_ABL(99) W32_LAUNCH_ABL(103) W32_LAUNCH_ABL(256)
+            W32_LAUNCH_ABL(1) W32_LAUNCH_ABL(2) W32_LAUNCH_ABL(3) W32_LAUNCH_ABL(4) W32_LAUNCH_ABL(7) W32_LAUNCH_ABL(32) W32_LAUNCH_ABL(96) W32_LAUNCH_ABL(99) W32_LAUNCH_ABL(103) W32_LAUNCH_ABL(256) W32_LAUNCH_ABL(512)
         }
 #undef W32_LAUNCH_ABL
     }
