@@ -83,6 +83,18 @@ def test_filter_gradient_plans_decide_which_ranges_the_step_clears(q, batch):
     assert q('yolo2_conv2d_wgrad_accumulates', 0, 13, 13, 8, 8, 8, 8, 3, BF16) == 1                          # bad arguments: be safe, clear
 
 
+def test_conv1_filter_gradient_plan_one_workgroup_stores_several_add(q):
+    """conv_wgrad_c32.hip (32 -> 64 channels, bf16, rows that are a multiple of 16 wide and fit its LDS ring): one workgroup per run of image rows;
+    a launch of ONE workgroup owns dW and stores (no clearing), several add atomically.  Shapes it does not take fall to the per-tap kernel's
+    plan (f32, channel strides other than 32 / 64, widths that are not a multiple of 16), which splits the pixels of a layer this size."""
+    BF16, F32 = 1, 0
+    def acc(B, H, W, dtype=BF16, ldx=32, ldy=64):
+        return q('yolo2_conv2d_wgrad_accumulates', B, H, W, 32, ldx, 64, ldy, 3, dtype)
+    assert acc(1, 1, 16) == 0 and acc(1, 1, 304) == 0                      # one image row: one workgroup
+    assert acc(1, 2, 16) == 1 and acc(16, 208, 208) == 1 and acc(8, 304, 304) == 1
+    assert acc(16, 208, 208, F32) == 1 and acc(16, 208, 208, BF16, 40, 64) == 1 and acc(16, 200, 200) == 1      # per-tap plan at the layer's size: 208 pixel ranges
+
+
 def test_arena_layout_alignment_and_bucket_bounds():
     """Every variable starts on a 256-byte boundary (a 425-element bias once shifted every later filter off the 128-byte lines) and
     gradient buckets end on variable boundaries."""
